@@ -1,0 +1,179 @@
+/* t2v_abi.h — C ABI of the MI355X-native denoising-step kernels (libt2v_hip.so).
+ *
+ * The reference (ExponentialML/Text-To-Video-Finetuning) has no FFI of its own: its hot path
+ * reaches native code through PyTorch leaf modules.  This header IS the drop-in
+ * boundary underneath the module-tree contract: every entry point replaces the native kernel
+ * that one reference call site dispatches to (cited per function).  Conventions:
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer;
+ *   - asynchronous on the given hipStream_t, no internal synchronisation, no allocation
+ *     (graph-capture safe); caller owns all memory incl. workspaces;
+ *   - returns 0 on success, negative T2V_E* on error; t2v_last_error() gives a thread-local text;
+ *   - activations are "token matrices": row-major [rows, ld] bf16, channels contiguous
+ *     (channels-last).  rows = images*H*W.  `ld` = row stride in ELEMENTS;
+ *   - accumulation, statistics, softmax, loss and optimizer state are fp32.
+ */
+#ifndef T2V_ABI_H
+#define T2V_ABI_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* t2v_stream_t; /* hipStream_t */
+
+#define T2V_OK 0
+#define T2V_EINVAL (-1)
+#define T2V_ELAUNCH (-2)
+#define T2V_ABI_VERSION 1
+
+int t2v_abi_version(void);
+const char* t2v_last_error(void);
+
+/* ---- sliding-window gather geometry (Conv2d 3x3/1x1/stride-2, Conv3d (3,1,1), their bwd-data) ----
+ * Output position p=(n,oy,ox) on the Ho x Wo grid, tap (ky,kx):
+ *   vy = oy*sy + ky - py ; vx = ox*sx + kx - px
+ *   if tdiv==2: position is valid only if vy,vx even; vy/=2, vx/=2      (bwd-data of a stride-2 conv)
+ *   valid iff 0<=vy<Hv && 0<=vx<Wv ; source row = (n*(Hv>>up) + (vy>>up))*(Wv>>up) + (vx>>up)
+ * `up`=1 reads a nearest-2x-upsampled view of a half-resolution source (Upsample2D,
+ * models/unet_3d_blocks.py:742,852).  The (3,1,1) temporal conv (TemporalConvLayer,
+ * models/unet_3d_blocks.py:308-314) is the case n=b, y=frame, x=pixel, KH=3, KW=1, py=1, px=0. */
+typedef struct {
+  int C;          /* channels per tap (K = KH*KW*C) */
+  int Hv, Wv;     /* (virtual) source grid */
+  int Ho, Wo;     /* output grid */
+  int KH, KW;
+  int sy, sx, py, px;
+  int tdiv;       /* 1 or 2 */
+  int up;         /* 0 or 1 */
+} T2VConvGeom;
+
+enum { T2V_A_DENSE = 0, T2V_A_CONV = 1 };
+enum { T2V_OUT_BF16 = 0, T2V_OUT_F32 = 1, T2V_OUT_F32_ATOMIC = 2 };
+enum { T2V_ACT_NONE = 0, T2V_ACT_SILU = 1 };
+
+/* D[M,N] = act( alpha * sum_k A[m,k]*B[n,k] + bias[n] + rowbias[m / rows_per_rb, n] ) + beta * R[m,n]
+ *
+ * Replaces (under torch autocast bf16, fp32 accumulate): F.linear / F.conv2d / F.conv3d of every
+ * nn.Linear / nn.Conv2d / nn.Conv3d on the path (ResnetBlock2D.conv1/conv2/conv_shortcut/time_emb_proj,
+ * TemporalConvLayer.conv1-4, Attention.to_q/k/v/out, GEGLU.proj, FeedForward, proj_in/out, conv_in/out,
+ * Down/Upsample2D.conv — wired at models/unet_3d_blocks.py:295-361,458-513,597-628,693-744,827-854 and
+ * models/unet_3d_condition.py:132-152,249-251), their backward-data passes, and — with a_trans/b_trans —
+ * the weight-gradient reductions (dW[n,k] = sum_m dY[m,n] X[m,k]) incl. the LoRA factor gradients
+ * (utils/lora.py:57-62,134-139,211-216).
+ *   a_trans=0: A is [M, K] (lda) or, a_mode=CONV, gathered rows of a [rows, lda] source, K ordered (tap, c)
+ *   a_trans=1: A is stored [K, M] (lda = stride between k rows)
+ *   b_trans=0: B is [N, K] (ldb)      b_trans=1: B stored [K, N] (ldb); with b_conv=1 the k rows of B
+ *              are gathered positions and N is ordered (tap, c)  (conv weight gradient)
+ * K%8==0, lda/ldb/ldd/ldr %8==0 (16-byte chunks); M,N arbitrary (edge tiles are predicated).
+ * batch>1: blockIdx.z batches with element strides; split_k>1 requires out_mode=F32_ATOMIC. */
+typedef struct {
+  int M, N, K;
+  const void* A; long long lda; int a_mode; int a_trans;
+  const void* B; long long ldb; int b_trans; int b_conv;
+  T2VConvGeom geom;
+  void* D; long long ldd; int out_mode;
+  const void* bias;            /* fp32 [N] or NULL */
+  const void* rowbias; long long ldrb; int rows_per_rb;   /* bf16 [M/rows_per_rb, N] or NULL */
+  const void* R; long long ldr;  /* bf16 residual or NULL */
+  float alpha, beta;
+  int act;
+  int batch; long long strideA, strideB, strideD, strideR;
+  int split_k;
+  /* optional dropout on (alpha*acc) BEFORE bias/residual — LoRA branch (utils/lora.py:49,119) */
+  float drop_p; unsigned long long drop_seed;
+} T2VGemm;
+int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
+
+/* direct small-channel conv (Cin<=8 or Cout<=8): conv_in 4->320, conv_out 320->4
+ * (models/unet_3d_condition.py:132-134,249-251), VAE conv_in 3->128, conv_out 512->8, quant_conv 8->8.
+ * x: [rows, ldx] bf16 channels-last (or fp32 NCHW when x_nchw_f32=1), w: fp32 [Cout, KH, KW, Cin], y: bf16 [rows_out, ldy] */
+typedef struct {
+  const void* x; long long ldx; int x_nchw_f32;
+  const float* w; const float* bias;
+  void* y; long long ldy; int y_nchw_f32;
+  int nimg, Cin, Cout; T2VConvGeom geom;
+} T2VSmallConv;
+int t2v_smallconv(const T2VSmallConv* p, t2v_stream_t stream);
+
+/* ---- GroupNorm (+SiLU) over channels-last data.  Replaces F.group_norm(+F.silu) of ResnetBlock2D.norm1/2,
+ * TemporalConvLayer.conv*[0:2], Transformer2DModel.norm, TransformerTemporalModel.norm, conv_norm_out
+ * (models/unet_3d_condition.py:239-243,488-490).  A "domain" = the rows one statistic spans: H*W rows
+ * (per-frame norms) or F*H*W rows (5-D temporal norms).  sums: fp32 [ndomains, G, 2] = (sum, sumsq), zeroed by caller. */
+int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows_per_domain, int C, int G,
+                 float* sums, t2v_stream_t stream);
+int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy, int ndomains, int rows_per_domain, int C, int G,
+                 const float* sums, const float* gamma, const float* beta, float eps, int silu,
+                 float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
+/* backward: bsums fp32 [ndomains,G,2] = (sum dxh, sum dxh*xh) zeroed by caller; dgamma/dbeta fp32 [C] accumulate (may be NULL) */
+int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long lddy, int ndomains, int rows_per_domain,
+                     int C, int G, const float* sums, const float* gamma, const float* beta, float eps, int silu,
+                     float drop_p, unsigned long long drop_seed,
+                     float* bsums, float* dgamma, float* dbeta, t2v_stream_t stream);
+int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
+                     int ndomains, int rows_per_domain, int C, int G, const float* sums, const float* bsums,
+                     const float* gamma, const float* beta, float eps, int silu,
+                     float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
+
+/* ---- LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3).  stats: fp32 [rows,2] = (mean, rstd). */
+int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int C, const float* gamma,
+                      const float* beta, float eps, float* stats, t2v_stream_t stream);
+int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int rows,
+                      int C, const float* gamma, const float* stats, float* dgamma, float* dbeta, t2v_stream_t stream);
+
+/* ---- scaled-dot-product attention core, head_dim 64, no mask (AttnProcessor2_0, train.py:138-139).
+ * One kernel serves temporal self (S=F, strided over frames), spatial self (S=H*W) and cross (Sk=77)
+ * attention through strides (ELEMENTS): element (batch b, position s, head h, dim d) of X lives at
+ *   X + (b / x_bdiv) * x_bstride_hi + (b % x_bdiv) * x_bstride_lo + s * x_sstride + h*64 + d
+ * lse: fp32 [nbatch, heads, Sq] log-sum-exp (saved for backward). */
+typedef struct {
+  const void* ptr; long long bstride_hi, bstride_lo, sstride; int bdiv;
+} T2VAttnOperand;
+typedef struct {
+  int nbatch, heads, Sq, Sk; float scale;
+  T2VAttnOperand q, k, v, o;
+  float* lse;
+  /* backward only */
+  T2VAttnOperand d_o, dq, dk, dv;
+  float* delta;   /* fp32 [nbatch, heads, Sq] workspace: rowsum(dO*O) */
+} T2VAttn;
+int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream);
+int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream);
+
+/* ---- elementwise ---- */
+/* GEGLU gate: y[m, j] = x[m, j] * gelu_erf(x[m, inner + j])  (FeedForward/GEGLU) */
+int t2v_geglu_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int inner, t2v_stream_t stream);
+int t2v_geglu_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int rows,
+                  int inner, t2v_stream_t stream);
+/* y = silu(x) on a flat bf16 array (temb activation, ResnetBlock2D) and its backward */
+int t2v_silu_fwd(const void* x, void* y, long long n, t2v_stream_t stream);
+int t2v_silu_bwd(const void* x, const void* dy, void* dx, long long n, t2v_stream_t stream);
+/* strided 2-D copy/add of bf16 token matrices (skip concat torch.cat, models/unet_3d_blocks.py:764,861; grad accumulation) */
+int t2v_copy2d(const void* x, long long ldx, void* y, long long ldy, int rows, int cols, int accumulate,
+               t2v_stream_t stream);
+/* 2x2 sum-pool of a [nimg, 2H, 2W, C] gradient into [nimg, H, W, C] (backward of nearest-2x upsample) */
+int t2v_pool2x2_sum(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
+                    t2v_stream_t stream);
+/* layout/dtype conversion at the 4-channel boundary: NCHW-like fp32 [n, C, rows] <-> channels-last bf16 [n*rows, ld] */
+int t2v_f32_planar_to_bf16_cl(const float* x, void* y, long long ldy, int n, int C, long long rows, t2v_stream_t stream);
+int t2v_bf16_cl_to_f32_planar(const void* x, long long ldx, float* y, int n, int C, long long rows, t2v_stream_t stream);
+/* fp32 <-> bf16 flat casts (weight preparation, gradient hand-off) */
+int t2v_cast_f32_to_bf16(const float* x, void* y, long long n, t2v_stream_t stream);
+int t2v_cast_bf16_to_f32(const void* x, float* y, long long n, int accumulate, t2v_stream_t stream);
+
+/* ---- loss and optimizer (train.py:827, 868-879) ---- */
+/* loss[0] += mean((pred-target)^2); dpred = 2*(pred-target)/n * gscale   (fp32, F.mse_loss) */
+int t2v_mse_fwd_bwd(const float* pred, const float* target, long long n, float* loss, float* dpred, float gscale,
+                    t2v_stream_t stream);
+/* out[0] += sum(x^2) over a flat fp32 buffer (global grad-norm, accelerator.clip_grad_norm_) */
+int t2v_sumsq(const float* x, long long n, float* out, t2v_stream_t stream);
+/* fused AdamW on flat fp32 buffers (torch.optim.AdamW semantics, train.py:238-249,598-604);
+ * sumsq: device pointer to sum of squared grads (clip coefficient = min(1, max_norm/(sqrt(sumsq)+1e-6))) or NULL;
+ * grads are scaled by grad_scale first (1/world_size after a SUM all-reduce). step = 1-based device counter incremented here. */
+int t2v_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+              float wd, const float* sumsq, float max_norm, float grad_scale, int* step, t2v_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,300 @@
+// attn.hip — scaled-dot-product attention core (head_dim 64, no mask), forward + backward, for gfx950.
+//
+// One wave64 owns a 32-row query block (fwd, dQ) or a 32-row key block (dK/dV) and streams the other
+// sequence in 32-row tiles; everything stays in registers (flash-style online softmax), MFMA 32x32x16 bf16:
+//   fwd : S^T = K Q^T (lane = query -> row max/sum are lane-local + one cross-half shuffle),
+//         O^T += V^T P^T  where P^T is fed straight from the S^T accumulator registers as the B operand and
+//         V^T fragments come from a wave-private LDS tile through ds_read_b64_tr_b16 (hardware transpose);
+//         the MFMA k-slot <-> key permutation implied by the accumulator layout is applied to both operands.
+//   dQ  : same layout, dS^T from registers, K^T via transpose reads.        (also produces delta = rowsum(dO*O))
+//   dKdV: S = Q K^T (lane = key), dV^T += dO^T P, dK^T += Q^T dS with Q^T/dO^T via transpose reads.
+// Strided operands (t2v_abi.h, T2VAttnOperand) let the same kernel serve temporal attention over frames
+// (sequence stride = H*W*C), per-frame spatial attention and text cross-attention without any permute copy.
+#include "common.h"
+
+namespace {
+
+constexpr int LDT = 96;  // LDS tile row stride (elements): 64 + 32 pad keeps the transpose reads conflict-free
+
+__device__ __forceinline__ long long op_off(const T2VAttnOperand& o, int b, int h) {
+  return (long long)(b / o.bdiv) * o.bstride_hi + (long long)(b % o.bdiv) * o.bstride_lo + h * 64;
+}
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ bf16x8 ldg8(const bf16_t* p, bool ok) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? *(const bf16x8*)p : z;
+}
+// stage a [32 rows][64] tile (rows r0.. of a strided sequence) into wave-private LDS
+__device__ __forceinline__ void stage_tile(bf16_t* s, const bf16_t* base, long long ss, int r0, int rmax, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = lane + 64 * i, rr = c >> 3, dch = c & 7;
+    bf16x8 v = ldg8(base + (long long)(r0 + rr) * ss + dch * 8, r0 + rr < rmax);
+    *(bf16x8*)(s + rr * LDT + dch * 8) = v;
+  }
+}
+// A-operand fragment of X^T (rows = 32 feature columns [32*fm, 32*fm+32), k = the 16 tile rows of k-step kk,
+// permuted exactly like the accumulator-register order) from an LDS tile X[row][feature]
+__device__ __forceinline__ bf16x8 trfrag(const bf16_t* s, int fm, int kk, int lane) {
+  int gq = lane >> 4, li = lane & 15;
+  int k0 = 16 * kk + 4 * (gq >> 1) + (li >> 2);
+  int col = 32 * fm + 16 * (gq & 1) + 4 * (li & 3);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(s + k0 * LDT + col));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(s + (k0 + 8) * LDT + col));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int kk) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[8 * kk + j]);
+  return o;
+}
+// store the lane's 32 values of a transposed accumulator pair (lane = row `row`, regs = features) as bf16
+__device__ __forceinline__ void store_rowT(bf16_t* base, long long ss, int row, const f32x16& a0, const f32x16& a1, float mul,
+                                           int hi) {
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x16& a = fm ? a1 : a0;
+      uint2 w;
+      w.x = pack2bf(a[4 * rq] * mul, a[4 * rq + 1] * mul);
+      w.y = pack2bf(a[4 * rq + 2] * mul, a[4 * rq + 3] * mul);
+      *(uint2*)(base + (long long)row * ss + 32 * fm + 8 * rq + 4 * hi) = w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const T2VAttn p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sV[32 * LDT];
+  const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  bf16_t* O = (bf16_t*)p.o.ptr + op_off(p.o, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const int q = qb * 32 + l31;
+  const bool qok = q < Sq;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) qf[kd] = ldg8(Q + (long long)q * p.q.sstride + 16 * kd + 8 * hi, qok);
+  float m = -INFINITY, l = 0.f;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+  for (int kt = 0; kt < Sk; kt += 32) {
+    const int key = kt + l31;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      bf16x8 kf = ldg8(K + (long long)key * p.k.sstride + 16 * kd + 8 * hi, key < Sk);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
+    }
+    stage_tile(sV, V, p.v.sstride, kt, Sk, lane);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sv = (kt + crow(r, hi) < Sk) ? s[r] * p.scale : -INFINITY;
+      s[r] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float pv = __expf(s[r] - mn);
+      s[r] = pv;
+      rs += pv;
+    }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 pb = pack8(s, kk);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sV, 0, kk, lane), pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sV, 1, kk, lane), pb, o1, 0, 0, 0);
+    }
+  }
+  if (qok) {
+    store_rowT(O, p.o.sstride, q, o0, o1, 1.f / l, hi);
+    if (hi == 0 && p.lse) p.lse[((long long)b * p.heads + h) * Sq + q] = m + __logf(l);
+  }
+}
+
+// dQ (and delta = rowsum(dO * O)); one wave per 32-query block
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[32 * LDT];
+  const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  const bf16_t* O = (const bf16_t*)p.o.ptr + op_off(p.o, b, h);
+  const bf16_t* dO = (const bf16_t*)p.d_o.ptr + op_off(p.d_o, b, h);
+  bf16_t* dQ = (bf16_t*)p.dq.ptr + op_off(p.dq, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const int q = qb * 32 + l31;
+  const bool qok = q < Sq;
+  bf16x8 qf[4], dof[4];
+  float dl = 0.f;
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) {
+    qf[kd] = ldg8(Q + (long long)q * p.q.sstride + 16 * kd + 8 * hi, qok);
+    dof[kd] = ldg8(dO + (long long)q * p.d_o.sstride + 16 * kd + 8 * hi, qok);
+    bf16x8 of = ldg8(O + (long long)q * p.o.sstride + 16 * kd + 8 * hi, qok);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += bf2f((unsigned short)of[e]) * bf2f((unsigned short)dof[kd][e]);
+  }
+  dl += __shfl_xor(dl, 32);
+  const long long sidx = ((long long)b * p.heads + h) * Sq + q;
+  if (qok && hi == 0) p.delta[sidx] = dl;
+  const float lse = qok ? p.lse[sidx] : 0.f;
+  f32x16 a0, a1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
+  for (int kt = 0; kt < Sk; kt += 32) {
+    const int key = kt + l31;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      bf16x8 kf = ldg8(K + (long long)key * p.k.sstride + 16 * kd + 8 * hi, key < Sk);
+      bf16x8 vf = ldg8(V + (long long)key * p.v.sstride + 16 * kd + 8 * hi, key < Sk);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kd], dp, 0, 0, 0);
+    }
+    stage_tile(sK, K, p.k.sstride, kt, Sk, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float pv = (kt + crow(r, hi) < Sk) ? __expf(s[r] * p.scale - lse) : 0.f;
+      s[r] = pv * (dp[r] - dl) * p.scale;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 db = pack8(s, kk);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sK, 0, kk, lane), db, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sK, 1, kk, lane), db, a1, 0, 0, 0);
+    }
+  }
+  if (qok) store_rowT(dQ, p.dq.sstride, q, a0, a1, 1.f, hi);
+}
+
+// dK, dV; one wave per 32-key block
+__global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_t sD[32 * LDT];
+  const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  const bf16_t* dO = (const bf16_t*)p.d_o.ptr + op_off(p.d_o, b, h);
+  bf16_t* dK = (bf16_t*)p.dk.ptr + op_off(p.dk, b, h);
+  bf16_t* dV = (bf16_t*)p.dv.ptr + op_off(p.dv, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const int key = kb * 32 + l31;
+  const bool kok = key < Sk;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) {
+    kf[kd] = ldg8(K + (long long)key * p.k.sstride + 16 * kd + 8 * hi, kok);
+    vf[kd] = ldg8(V + (long long)key * p.v.sstride + 16 * kd + 8 * hi, kok);
+  }
+  const float* lsep = p.lse + ((long long)b * p.heads + h) * Sq;
+  const float* dlp = p.delta + ((long long)b * p.heads + h) * Sq;
+  f32x16 k0, k1, v0, v1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) k0[r] = k1[r] = v0[r] = v1[r] = 0.f;
+  for (int qt = 0; qt < Sq; qt += 32) {
+    const int qrow = qt + l31;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      bf16x8 qa = ldg8(Q + (long long)qrow * p.q.sstride + 16 * kd + 8 * hi, qrow < Sq);
+      bf16x8 da = ldg8(dO + (long long)qrow * p.d_o.sstride + 16 * kd + 8 * hi, qrow < Sq);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kd], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kd], dp, 0, 0, 0);
+    }
+    stage_tile(sQ, Q, p.q.sstride, qt, Sq, lane);
+    stage_tile(sD, dO, p.d_o.sstride, qt, Sq, lane);
+    f32x16 pr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = qt + crow(r, hi);
+      const bool ok = (qr < Sq) && kok;
+      const float L = ok ? lsep[qr] : 0.f;
+      const float D = ok ? dlp[qr] : 0.f;
+      float pv = ok ? __expf(s[r] * p.scale - L) : 0.f;
+      pr[r] = pv;
+      s[r] = pv * (dp[r] - D) * p.scale;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 pb = pack8(pr, kk), db = pack8(s, kk);
+      v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sD, 0, kk, lane), pb, v0, 0, 0, 0);
+      v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sD, 1, kk, lane), pb, v1, 0, 0, 0);
+      k0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sQ, 0, kk, lane), db, k0, 0, 0, 0);
+      k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sQ, 1, kk, lane), db, k1, 0, 0, 0);
+    }
+  }
+  if (kok) {
+    store_rowT(dK, p.dk.sstride, key, k0, k1, 1.f, hi);
+    store_rowT(dV, p.dv.sstride, key, v0, v1, 1.f, hi);
+  }
+}
+
+int check_op(const char* fn, const char* name, const T2VAttnOperand& o) {
+  if (!o.ptr || o.bdiv <= 0 || ((uintptr_t)o.ptr & 15) || (o.sstride % 8) || (o.bstride_hi % 8) || (o.bstride_lo % 8)) {
+    t2v_set_error("%s: operand %s invalid (ptr %p, bdiv %d, strides must be multiples of 8 elements)", fn, name, o.ptr,
+                  o.bdiv);
+    return T2V_EINVAL;
+  }
+  return T2V_OK;
+}
+}  // namespace
+
+extern "C" int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream) {
+  T2V_CHECK_ARG(p && p->nbatch > 0 && p->heads > 0 && p->Sq > 0 && p->Sk > 0, "t2v_attn_fwd: bad dims");
+  if (int e = check_op("t2v_attn_fwd", "q", p->q)) return e;
+  if (int e = check_op("t2v_attn_fwd", "k", p->k)) return e;
+  if (int e = check_op("t2v_attn_fwd", "v", p->v)) return e;
+  if (int e = check_op("t2v_attn_fwd", "o", p->o)) return e;
+  dim3 grid((p->Sq + 31) / 32, p->heads, p->nbatch);
+  T2V_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "t2v_attn_fwd: heads/nbatch exceed grid limits (%d, %d)", p->heads,
+                p->nbatch);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
+  T2V_CHECK_ARG(p && p->nbatch > 0 && p->heads > 0 && p->Sq > 0 && p->Sk > 0, "t2v_attn_bwd: bad dims");
+  T2V_CHECK_ARG(p->lse && p->delta, "t2v_attn_bwd: lse and delta are required");
+  const T2VAttnOperand* ops[] = {&p->q, &p->k, &p->v, &p->o, &p->d_o, &p->dq, &p->dk, &p->dv};
+  const char* names[] = {"q", "k", "v", "o", "d_o", "dq", "dk", "dv"};
+  for (int i = 0; i < 8; ++i)
+    if (int e = check_op("t2v_attn_bwd", names[i], *ops[i])) return e;
+  T2V_CHECK_ARG(p->heads <= 65535 && p->nbatch <= 65535, "t2v_attn_bwd: heads/nbatch exceed grid limits");
+  dim3 gq((p->Sq + 31) / 32, p->heads, p->nbatch);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
+  T2V_CHECK_LAUNCH();
+  dim3 gk((p->Sk + 31) / 32, p->heads, p->nbatch);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}

@@ -1,0 +1,62 @@
+// common.h — shared device helpers for the gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "t2v_abi.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 16-byte chunk = 8 bf16
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(2))) short bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// counter-based dropout keep decision: splitmix64 of (seed, element index)
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, float p) {
+  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+void t2v_set_error(const char* fmt, ...);
+#define T2V_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      t2v_set_error(__VA_ARGS__);         \
+      return T2V_EINVAL;                  \
+    }                                     \
+  } while (0)
+#define T2V_CHECK_LAUNCH()                                              \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      t2v_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return T2V_ELAUNCH;                                               \
+    }                                                                   \
+  } while (0)

@@ -1,0 +1,337 @@
+// elementwise.hip — HBM-bound streaming kernels: GEGLU gate, SiLU, strided copy/add (skip concat), 2x2 sum-pool,
+// layout/dtype conversion at the 4-channel latent boundary, small-channel direct convolution, MSE loss,
+// global grad-norm and fused AdamW.  16-byte accesses per lane, grid-stride loops, fp32 math.
+#include <stdarg.h>
+#include "common.h"
+
+// ------------------------------------------------------------------ error plumbing (thread-local, see t2v_abi.h)
+static thread_local char g_err[512] = "";
+void t2v_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* t2v_last_error(void) { return g_err; }
+extern "C" int t2v_abi_version(void) { return T2V_ABI_VERSION; }
+
+namespace {
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+inline int grid_for(long long n) { return (int)max(1LL, min((n + 255) / 256, (long long)16384)); }
+
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
+                                                         long long ldy, long long rows, int inner) {
+  const int cpr = inner >> 3;
+  const long long n = rows * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    long long r = i / cpr;
+    int c = (int)(i - r * cpr) * 8;
+    bf16x8 h = *(const bf16x8*)(x + r * ldx + c);
+    bf16x8 g = *(const bf16x8*)(x + r * ldx + inner + c);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bf2f((unsigned short)h[e]) * gelu_erf(bf2f((unsigned short)g[e])));
+    *(bf16x8*)(y + r * ldy + c) = o;
+  }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                         const bf16_t* __restrict__ dy, long long lddy,
+                                                         bf16_t* __restrict__ dx, long long lddx, long long rows, int inner) {
+  const int cpr = inner >> 3;
+  const long long n = rows * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    long long r = i / cpr;
+    int c = (int)(i - r * cpr) * 8;
+    bf16x8 h = *(const bf16x8*)(x + r * ldx + c);
+    bf16x8 g = *(const bf16x8*)(x + r * ldx + inner + c);
+    bf16x8 d = *(const bf16x8*)(dy + r * lddy + c);
+    bf16x8 oh, og;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float hf = bf2f((unsigned short)h[e]), gf = bf2f((unsigned short)g[e]), df = bf2f((unsigned short)d[e]);
+      oh[e] = (short)f2bf(df * gelu_erf(gf));
+      og[e] = (short)f2bf(df * hf * gelu_erf_grad(gf));
+    }
+    *(bf16x8*)(dx + r * lddx + c) = oh;
+    *(bf16x8*)(dx + r * lddx + inner + c) = og;
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                    bf16_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = bf2f(x[i]);
+    float out;
+    if (dy) {
+      float sg = sigmoid_f(v);
+      out = bf2f(dy[i]) * sg * (1.f + v * (1.f - sg));
+    } else {
+      out = silu_f(v);
+    }
+    y[i] = f2bf(out);
+  }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
+                                                      long long ldy, long long rows, int cols, int accumulate) {
+  const int cpr = cols >> 3;
+  const long long n = rows * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    long long r = i / cpr;
+    int c = (int)(i - r * cpr) * 8;
+    bf16x8 v = *(const bf16x8*)(x + r * ldx + c);
+    if (accumulate) {
+      bf16x8 o = *(const bf16x8*)(y + r * ldy + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((unsigned short)v[e]) + bf2f((unsigned short)o[e]));
+    }
+    *(bf16x8*)(y + r * ldy + c) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool2x2_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
+                                                       long long ldy, int nimg, int H, int W, int C) {
+  const int cpr = C >> 3;
+  const long long n = (long long)nimg * H * W * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    long long pos = i / cpr;
+    int c = (int)(i - pos * cpr) * 8;
+    int xw = (int)(pos % W);
+    long long t = pos / W;
+    int yh = (int)(t % H);
+    long long img = t / H;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        long long srow = (img * 2 * H + 2 * yh + dy) * (2 * W) + 2 * xw + dx;
+        bf16x8 v = *(const bf16x8*)(x + srow * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f((unsigned short)v[e]);
+      }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(acc[e]);
+    *(bf16x8*)(y + pos * ldy + c) = o;
+  }
+}
+
+// planar fp32 [n, C, rows] <-> channels-last bf16 [n*rows, ld]   (C small: 3, 4, 8)
+__global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long ldy,
+                                                            int n, int C, long long rows) {
+  const long long tot = (long long)n * rows;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+    long long img = i / rows, r = i - img * rows;
+    for (int c = 0; c < C; ++c) y[i * ldy + c] = f2bf(x[(img * C + c) * rows + r]);
+  }
+}
+__global__ __launch_bounds__(256) void cl_to_planar_kernel(const bf16_t* __restrict__ x, long long ldx, float* __restrict__ y,
+                                                            int n, int C, long long rows) {
+  const long long tot = (long long)n * rows;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+    long long img = i / rows, r = i - img * rows;
+    for (int c = 0; c < C; ++c) y[(img * C + c) * rows + r] = bf2f(x[i * ldx + c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      float4 v = *(const float4*)(x + i);
+      uint2 o;
+      o.x = pack2bf(v.x, v.y);
+      o.y = pack2bf(v.z, v.w);
+      *(uint2*)(y + i) = o;
+    } else {
+      for (long long j = i; j < n; ++j) y[j] = f2bf(x[j]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n,
+                                                        int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = bf2f(x[i]);
+    y[i] = accumulate ? y[i] + v : v;
+  }
+}
+
+// direct convolution for tiny channel counts: one thread per (output position, output channel)
+__global__ __launch_bounds__(256) void smallconv_kernel(const T2VSmallConv p) {
+  const T2VConvGeom g = p.geom;
+  const long long npos = (long long)p.nimg * g.Ho * g.Wo;
+  const long long tot = npos * p.Cout;
+  const int Hr = g.Hv >> g.up, Wr = g.Wv >> g.up;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+    const long long pos = i / p.Cout;
+    const int co = (int)(i - pos * p.Cout);
+    const int ox = (int)(pos % g.Wo);
+    const long long t = pos / g.Wo;
+    const int oy = (int)(t % g.Ho);
+    const long long img = t / g.Ho;
+    float acc = p.bias ? p.bias[co] : 0.f;
+    for (int ky = 0; ky < g.KH; ++ky)
+      for (int kx = 0; kx < g.KW; ++kx) {
+        int vy = oy * g.sy + ky - g.py, vx = ox * g.sx + kx - g.px;
+        if ((unsigned)vy >= (unsigned)g.Hv || (unsigned)vx >= (unsigned)g.Wv) continue;
+        const int ry = vy >> g.up, rx = vx >> g.up;
+        const float* w = p.w + ((long long)(co * g.KH + ky) * g.KW + kx) * p.Cin;
+        if (p.x_nchw_f32) {
+          const float* xs = (const float*)p.x + ((img * p.Cin) * Hr + ry) * (long long)Wr + rx;
+          for (int c = 0; c < p.Cin; ++c) acc += w[c] * xs[(long long)c * Hr * Wr];
+        } else {
+          const bf16_t* xs = (const bf16_t*)p.x + ((img * Hr + ry) * Wr + rx) * p.ldx;
+          for (int c = 0; c < p.Cin; ++c) acc += w[c] * bf2f(xs[c]);
+        }
+      }
+    if (p.y_nchw_f32)
+      ((float*)p.y)[((img * p.Cout + co) * g.Ho + oy) * (long long)g.Wo + ox] = acc;
+    else
+      ((bf16_t*)p.y)[pos * p.ldy + co] = f2bf(acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, long long n,
+                                                   float* __restrict__ loss, float* __restrict__ dpred, float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv = 1.f / (float)n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float d = pred[i] - target[i];
+    acc += d * d;
+    if (dpred) dpred[i] = 2.f * d * inv * gscale;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.AdamW (decoupled weight decay, bias correction, eps outside the sqrt of v_hat)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                     float wd, const float* __restrict__ sumsq, float max_norm, float grad_scale,
+                                                     const int* __restrict__ step) {
+  const int t = *step + 1;
+  float clip = grad_scale;
+  if (sumsq) {
+    float norm = sqrtf(*sumsq) * grad_scale;
+    clip *= fminf(1.f, max_norm / (norm + 1e-6f));
+  }
+  const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+  const float step_size = lr / bc1, ibc2s = rsqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float gi = g[i] * clip;
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) * ibc2s + eps);
+  }
+}
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+
+}  // namespace
+
+#define LAUNCH1D(kern, n, s, ...)                                                           \
+  hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__); \
+  T2V_CHECK_LAUNCH();                                                                       \
+  return T2V_OK
+
+extern "C" int t2v_geglu_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int inner, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && rows > 0 && inner > 0 && inner % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_geglu_fwd: bad args");
+  LAUNCH1D(geglu_fwd_kernel, (long long)rows * (inner >> 3), s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (long long)rows, inner);
+}
+extern "C" int t2v_geglu_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int rows,
+                             int inner, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && dy && dx && rows > 0 && inner % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
+                "t2v_geglu_bwd: bad args");
+  LAUNCH1D(geglu_bwd_kernel, (long long)rows * (inner >> 3), s, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx,
+           lddx, (long long)rows, inner);
+}
+extern "C" int t2v_silu_fwd(const void* x, void* y, long long n, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && n > 0, "t2v_silu_fwd: bad args");
+  LAUNCH1D(silu_kernel, n, s, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n);
+}
+extern "C" int t2v_silu_bwd(const void* x, const void* dy, void* dx, long long n, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && dy && dx && n > 0, "t2v_silu_bwd: bad args");
+  LAUNCH1D(silu_kernel, n, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
+}
+extern "C" int t2v_copy2d(const void* x, long long ldx, void* y, long long ldy, int rows, int cols, int accumulate,
+                          t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_copy2d: bad args");
+  T2V_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "t2v_copy2d: pointers must be 16-byte aligned");
+  LAUNCH1D(copy2d_kernel, (long long)rows * (cols >> 3), s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (long long)rows, cols,
+           accumulate);
+}
+extern "C" int t2v_pool2x2_sum(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
+                               t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && nimg > 0 && H > 0 && W > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_pool2x2_sum: bad args");
+  LAUNCH1D(pool2x2_kernel, (long long)nimg * H * W * (C >> 3), s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, nimg, H, W, C);
+}
+extern "C" int t2v_f32_planar_to_bf16_cl(const float* x, void* y, long long ldy, int n, int C, long long rows,
+                                         t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && n > 0 && C > 0 && rows > 0 && ldy >= C, "t2v_f32_planar_to_bf16_cl: bad args");
+  LAUNCH1D(planar_to_cl_kernel, (long long)n * rows, s, x, (bf16_t*)y, ldy, n, C, rows);
+}
+extern "C" int t2v_bf16_cl_to_f32_planar(const void* x, long long ldx, float* y, int n, int C, long long rows,
+                                         t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && n > 0 && C > 0 && rows > 0 && ldx >= C, "t2v_bf16_cl_to_f32_planar: bad args");
+  LAUNCH1D(cl_to_planar_kernel, (long long)n * rows, s, (const bf16_t*)x, ldx, y, n, C, rows);
+}
+extern "C" int t2v_cast_f32_to_bf16(const float* x, void* y, long long n, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && n > 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, "t2v_cast_f32_to_bf16: bad args");
+  LAUNCH1D(cast_f2b_kernel, (n + 3) / 4, s, x, (bf16_t*)y, n);
+}
+extern "C" int t2v_cast_bf16_to_f32(const void* x, float* y, long long n, int accumulate, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && n > 0, "t2v_cast_bf16_to_f32: bad args");
+  LAUNCH1D(cast_b2f_kernel, n, s, (const bf16_t*)x, y, n, accumulate);
+}
+extern "C" int t2v_smallconv(const T2VSmallConv* p, t2v_stream_t s) {
+  T2V_CHECK_ARG(p && p->x && p->w && p->y && p->nimg > 0 && p->Cin > 0 && p->Cout > 0, "t2v_smallconv: bad args");
+  T2V_CHECK_ARG(p->geom.tdiv == 1, "t2v_smallconv: tdiv must be 1");
+  long long tot = (long long)p->nimg * p->geom.Ho * p->geom.Wo * p->Cout;
+  LAUNCH1D(smallconv_kernel, tot, s, *p);
+}
+extern "C" int t2v_mse_fwd_bwd(const float* pred, const float* target, long long n, float* loss, float* dpred, float gscale,
+                               t2v_stream_t s) {
+  T2V_CHECK_ARG(pred && target && loss && n > 0, "t2v_mse_fwd_bwd: bad args");
+  hipLaunchKernelGGL(mse_kernel, dim3((int)max(1LL, min((n + 255) / 256, 1024LL))), dim3(256), 0, (hipStream_t)s, pred, target,
+                     n, loss, dpred, gscale);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+extern "C" int t2v_sumsq(const float* x, long long n, float* out, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && out && n > 0, "t2v_sumsq: bad args");
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)max(1LL, min((n + 255) / 256, 2048LL))), dim3(256), 0, (hipStream_t)s, x, n, out);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+extern "C" int t2v_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                         float wd, const float* sumsq, float max_norm, float grad_scale, int* step, t2v_stream_t s) {
+  T2V_CHECK_ARG(p && g && m && v && step && n > 0, "t2v_adamw: bad args");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, b1, b2, eps, wd, sumsq,
+                     max_norm, grad_scale, step);
+  T2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}

@@ -1,0 +1,409 @@
+// norm.hip — GroupNorm(+SiLU) and LayerNorm, forward and backward, over channels-last bf16 token matrices.
+// HBM-bound streaming kernels: 16-byte (8 x bf16) loads per lane, fp32 statistics, wave/LDS reductions,
+// one atomic per (block, group).  A GroupNorm "domain" is the set of rows one statistic spans
+// (H*W rows for per-frame norms, F*H*W rows for the 5-D temporal norms) — see t2v_abi.h.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ GroupNorm statistics
+// grid (nsplit, ndomains); each block reduces a slab of rows of one domain over all channels.
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                        const bf16_t* __restrict__ dy, long long lddy,
+                                                        int rows_per_domain, int C, int G, const float* __restrict__ sums,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int silu, float drop_p, unsigned long long drop_seed,
+                                                        float* __restrict__ out, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+  extern __shared__ float sbin[];  // [G][2]
+  const int d = blockIdx.y, tid = threadIdx.x;
+  const int tpr = C >> 3, rpp = 256 / tpr;
+  const int cc = tid % tpr, rl = tid / tpr;
+  const int cpg = C / G;
+  for (int i = tid; i < 2 * G; i += 256) sbin[i] = 0.f;
+  __syncthreads();
+  const int rows_per_split = (rows_per_domain + gridDim.x - 1) / gridDim.x;
+  const int rbeg = blockIdx.x * rows_per_split, rend = min(rows_per_domain, rbeg + rows_per_split);
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  float mean[8], rstd[8], gm[8], bt[8];
+  if (BWD) {
+    const float cnt = (float)rows_per_domain * cpg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = cc * 8 + e;
+      if (rl < rpp) {
+        int gi = c / cpg;
+        float mu = sums[(d * G + gi) * 2] / cnt;
+        float var = fmaxf(sums[(d * G + gi) * 2 + 1] / cnt - mu * mu, 0.f);
+        mean[e] = mu;
+        rstd[e] = rsqrtf(var + eps);
+        gm[e] = gamma[c];
+        bt[e] = beta[c];
+      }
+    }
+  }
+  if (rl < rpp) {
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int r = rbeg + rl; r < rend; r += rpp) {
+      const long long row = (long long)d * rows_per_domain + r;
+      bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
+      if (!BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = bf2f((unsigned short)xv[e]);
+          s0[e] += v;
+          s1[e] += v * v;
+        }
+      } else {
+        bf16x8 gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
+          float dz = bf2f((unsigned short)gv[e]);
+          if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
+          if (silu) {
+            float zz = xh * gm[e] + bt[e];
+            float sg = sigmoid_f(zz);
+            dz *= sg * (1.f + zz * (1.f - sg));
+          }
+          s0[e] += dz * gm[e];           // sum dxh
+          s1[e] += dz * gm[e] * xh;      // sum dxh * xh
+          if (dgamma) {                  // reuse mean/rstd regs? keep separate accumulators in LDS-free form
+            // per-channel parameter grads are accumulated below through atomics on (dz*xh, dz)
+          }
+        }
+      }
+    }
+    // per-channel parameter gradients (full finetune only): second light pass keeps register pressure low
+    if (BWD && dgamma) {
+      float a0[8], a1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+      for (int r = rbeg + rl; r < rend; r += rpp) {
+        const long long row = (long long)d * rows_per_domain + r;
+        bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
+        bf16x8 gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
+          float dz = bf2f((unsigned short)gv[e]);
+          if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
+          if (silu) {
+            float zz = xh * gm[e] + bt[e];
+            float sg = sigmoid_f(zz);
+            dz *= sg * (1.f + zz * (1.f - sg));
+          }
+          a0[e] += dz * xh;
+          a1[e] += dz;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(dgamma + cc * 8 + e, a0[e]);
+        atomicAdd(dbeta + cc * 8 + e, a1[e]);
+      }
+    }
+    int gi = (cc * 8) / cpg, rem = (cc * 8) - gi * cpg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&sbin[gi * 2], s0[e]);
+      atomicAdd(&sbin[gi * 2 + 1], s1[e]);
+      if (++rem == cpg) {
+        rem = 0;
+        ++gi;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * G; i += 256) atomicAdd(out + (long long)d * G * 2 + i, sbin[i]);
+}
+
+// ------------------------------------------------------------------ GroupNorm apply (fwd) / dx (bwd)
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                        const bf16_t* __restrict__ dy, long long lddy,
+                                                        bf16_t* __restrict__ y, long long ldy, long long nrows,
+                                                        int rows_per_domain, int C, int G, const float* __restrict__ sums,
+                                                        const float* __restrict__ bsums, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int silu, float drop_p,
+                                                        unsigned long long drop_seed) {
+  const int tpr = C >> 3, cpg = C / G;
+  const float cnt = (float)rows_per_domain * cpg, icnt = 1.f / cnt;
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const long long nchunks = nrows * tpr;
+  for (long long ci = (long long)blockIdx.x * 256 + threadIdx.x; ci < nchunks; ci += (long long)gridDim.x * 256) {
+    const long long row = ci / tpr;
+    const int cc = (int)(ci - row * tpr);
+    const int d = (int)(row / rows_per_domain);
+    bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
+    bf16x8 gv;
+    if (BWD) gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
+    int gi = (cc * 8) / cpg, rem = (cc * 8) - gi * cpg;
+    float mu = 0.f, rs = 0.f, b1 = 0.f, b2 = 0.f;
+    bool fresh = true;
+    bf16x8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (fresh) {
+        const float* sp = sums + ((long long)d * G + gi) * 2;
+        mu = sp[0] * icnt;
+        rs = rsqrtf(fmaxf(sp[1] * icnt - mu * mu, 0.f) + eps);
+        if (BWD) {
+          const float* bp = bsums + ((long long)d * G + gi) * 2;
+          b1 = bp[0] * icnt;
+          b2 = bp[1] * icnt;
+        }
+        fresh = false;
+      }
+      const int c = cc * 8 + e;
+      const float xh = (bf2f((unsigned short)xv[e]) - mu) * rs;
+      float out;
+      if (!BWD) {
+        float zz = xh * gamma[c] + beta[c];
+        if (silu) zz = silu_f(zz);
+        if (drop_p > 0.f) zz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? zz * ks : 0.f;
+        out = zz;
+      } else {
+        float dz = bf2f((unsigned short)gv[e]);
+        if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? dz * ks : 0.f;
+        if (silu) {
+          float zz = xh * gamma[c] + beta[c];
+          float sg = sigmoid_f(zz);
+          dz *= sg * (1.f + zz * (1.f - sg));
+        }
+        out = rs * (dz * gamma[c] - b1 - xh * b2);
+      }
+      ov[e] = (short)f2bf(out);
+      if (++rem == cpg) {
+        rem = 0;
+        ++gi;
+        fresh = true;
+      }
+    }
+    *(bf16x8*)(y + row * ldy + cc * 8) = ov;
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+constexpr int LN_MAXCH = 4;  // chunks of 8 per lane -> C <= 2048
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
+                                                      long long ldy, int rows, int C, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  for (long long row = (long long)blockIdx.x * 4 + wv; row < rows; row += (long long)gridDim.x * 4) {
+    float v[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int ch = lane + 64 * i;
+      if (ch < nch) {
+        bf16x8 xv = *(const bf16x8*)(x + row * ldx + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[i][e] = bf2f((unsigned short)xv[e]);
+          s += v[i][e];
+        }
+      }
+    }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float dlt = v[i][e] - mu;
+          q += dlt * dlt;
+        }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    if (lane == 0 && stats) {
+      stats[row * 2] = mu;
+      stats[row * 2 + 1] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int ch = lane + 64 * i;
+      if (ch < nch) {
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf((v[i][e] - mu) * rs * gamma[ch * 8 + e] + beta[ch * 8 + e]);
+        *(bf16x8*)(y + row * ldy + ch * 8) = ov;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                      const bf16_t* __restrict__ dy, long long lddy,
+                                                      bf16_t* __restrict__ dx, long long lddx, int rows, int C,
+                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
+  if (dgamma) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ag[i][e] = ab[i][e] = 0.f;
+  }
+  for (long long row = (long long)blockIdx.x * 4 + wv; row < rows; row += (long long)gridDim.x * 4) {
+    const float mu = stats[row * 2], rs = stats[row * 2 + 1];
+    float xh[LN_MAXCH][8], dh[LN_MAXCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int ch = lane + 64 * i;
+      if (ch < nch) {
+        bf16x8 xv = *(const bf16x8*)(x + row * ldx + ch * 8);
+        bf16x8 gv = *(const bf16x8*)(dy + row * lddy + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float h = (bf2f((unsigned short)xv[e]) - mu) * rs;
+          float g = bf2f((unsigned short)gv[e]);
+          if (dgamma) {
+            ag[i][e] += g * h;
+            ab[i][e] += g;
+          }
+          float dd = g * gamma[ch * 8 + e];
+          xh[i][e] = h;
+          dh[i][e] = dd;
+          s1 += dd;
+          s2 += dd * h;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int ch = lane + 64 * i;
+      if (ch < nch) {
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2));
+        *(bf16x8*)(dx + row * lddx + ch * 8) = ov;
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(dgamma + ch * 8 + e, ag[i][e]);
+          atomicAdd(dbeta + ch * 8 + e, ab[i][e]);
+        }
+      }
+    }
+  }
+}
+
+int gn_check(const char* fn, int C, int G, long long ldx) {
+  if (C <= 0 || G <= 0 || C % G != 0 || C % 8 != 0 || C > 2048 || ldx % 8 != 0) {
+    t2v_set_error("%s: need C%%G==0, C%%8==0, C<=2048, ld%%8==0 (C=%d G=%d ld=%lld)", fn, C, G, ldx);
+    return T2V_EINVAL;
+  }
+  return T2V_OK;
+}
+int gn_splits(int ndomains, int rows_per_domain, int C) {
+  int rpp = 256 / (C >> 3);
+  int want = max(1, 2048 / max(1, ndomains));
+  int maxs = max(1, rows_per_domain / (rpp * 4));
+  return max(1, min(want, maxs));
+}
+}  // namespace
+
+extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows_per_domain, int C, int G, float* sums,
+                            t2v_stream_t stream) {
+  if (int e = gn_check("t2v_gn_stats", C, G, ldx)) return e;
+  T2V_CHECK_ARG(x && sums && ndomains > 0 && rows_per_domain > 0, "t2v_gn_stats: bad args");
+  dim3 grid(gn_splits(ndomains, rows_per_domain, C), ndomains);
+  hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 2 * G * sizeof(float), (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, nullptr, 0, rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull,
+                     sums, nullptr, nullptr);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy, int ndomains, int rows_per_domain, int C,
+                            int G, const float* sums, const float* gamma, const float* beta, float eps, int silu,
+                            float drop_p, unsigned long long drop_seed, t2v_stream_t stream) {
+  if (int e = gn_check("t2v_gn_apply", C, G, ldx)) return e;
+  T2V_CHECK_ARG(x && y && sums && gamma && beta && ldy % 8 == 0, "t2v_gn_apply: bad args");
+  long long nrows = (long long)ndomains * rows_per_domain;
+  long long nchunks = nrows * (C >> 3);
+  int grid = (int)min((nchunks + 255) / 256, (long long)8192);
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
+                     0, (bf16_t*)y, ldy, nrows, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p,
+                     drop_seed);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long lddy, int ndomains,
+                                int rows_per_domain, int C, int G, const float* sums, const float* gamma, const float* beta,
+                                float eps, int silu, float drop_p, unsigned long long drop_seed, float* bsums, float* dgamma,
+                                float* dbeta, t2v_stream_t stream) {
+  if (int e = gn_check("t2v_gn_bwd_stats", C, G, ldx)) return e;
+  T2V_CHECK_ARG(x && dy && sums && gamma && beta && bsums && lddy % 8 == 0, "t2v_gn_bwd_stats: bad args");
+  T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_gn_bwd_stats: dgamma/dbeta must both be set or NULL");
+  dim3 grid(gn_splits(ndomains, rows_per_domain, C), ndomains);
+  hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 2 * G * sizeof(float), (hipStream_t)stream, (const bf16_t*)x,
+                     ldx, (const bf16_t*)dy, lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed,
+                     bsums, dgamma, dbeta);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
+                                int ndomains, int rows_per_domain, int C, int G, const float* sums, const float* bsums,
+                                const float* gamma, const float* beta, float eps, int silu, float drop_p,
+                                unsigned long long drop_seed, t2v_stream_t stream) {
+  if (int e = gn_check("t2v_gn_bwd_apply", C, G, ldx)) return e;
+  T2V_CHECK_ARG(x && dy && dx && sums && bsums && gamma && beta && lddy % 8 == 0 && lddx % 8 == 0,
+                "t2v_gn_bwd_apply: bad args");
+  long long nrows = (long long)ndomains * rows_per_domain;
+  long long nchunks = nrows * (C >> 3);
+  int grid = (int)min((nchunks + 255) / 256, (long long)8192);
+  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nrows, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,
+                     silu, drop_p, drop_seed);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int C, const float* gamma,
+                                 const float* beta, float eps, float* stats, t2v_stream_t stream) {
+  T2V_CHECK_ARG(x && y && gamma && beta && rows > 0, "t2v_layernorm_fwd: bad args");
+  T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_layernorm_fwd: need C%%8==0, C<=2048 (C=%d)", C);
+  int grid = min((rows + 3) / 4, 16384);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
+                     rows, C, gamma, beta, eps, stats);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
+                                 int rows, int C, const float* gamma, const float* stats, float* dgamma, float* dbeta,
+                                 t2v_stream_t stream) {
+  T2V_CHECK_ARG(x && dy && dx && gamma && stats && rows > 0, "t2v_layernorm_bwd: bad args");
+  T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
+                "t2v_layernorm_bwd: need C%%8==0, C<=2048 (C=%d)", C);
+  T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_layernorm_bwd: dgamma/dbeta must both be set or NULL");
+  int grid = min((rows + 3) / 4, dgamma ? 1024 : 16384);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, dgamma, dbeta);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}

@@ -1,0 +1,517 @@
+"""Autograd-aware operators of the native path: thin torch.autograd.Function wrappers around the C ABI.
+
+Activations are bf16 "token matrices" `[rows, C]` (channels-last; rows = images*H*W, unit inner stride,
+row stride = `ld`).  Every op here launches hand-written HIP kernels through `native.call`; nothing
+falls back to torch math on the device path (torch is used for allocation, views and the tiny
+reductions of bias-like gradients).
+
+Reference call sites replaced (all un-vendored diffusers leaves, see include/t2v_abi.h):
+nn.Linear / nn.Conv2d / nn.Conv3d forward+backward, F.group_norm(+silu), F.layer_norm,
+F.scaled_dot_product_attention (AttnProcessor2_0, train.py:138-139), GEGLU, SiLU.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import native as nv
+
+BF16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------- helpers
+def _mat(t, name="tensor"):
+    if t.dim() != 2 or t.dtype != BF16 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"t2v_amd: {name} must be a 2-D bf16 matrix with unit inner stride, got "
+                           f"{tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    nv.require_cuda(t)
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def ceil8(n):
+    return (n + 7) // 8 * 8
+
+
+@dataclass(frozen=True)
+class ConvCfg:
+    """Geometry of one sliding-window layer.  kind: 'linear' | 'conv' (2-D window over an (nimg,H,W) grid;
+    the (3,1,1) temporal Conv3d is the window KH=3,KW=1 over the grid (B, F, H*W))."""
+    kind: str = "linear"
+    nimg: int = 1
+    H: int = 1           # real source grid
+    W: int = 1
+    KH: int = 1
+    KW: int = 1
+    stride: int = 1
+    pad_y: int = 0
+    pad_x: int = 0
+    up: int = 0          # 1: source is nearest-2x upsampled on the fly (Upsample2D)
+    Ho: int = 1
+    Wo: int = 1
+
+    @staticmethod
+    def conv2d(nimg, H, W, k=3, stride=1, pad=1, up=0, Ho=None, Wo=None):
+        Hv, Wv = H << up, W << up
+        if Ho is None:
+            Ho = (Hv + 2 * pad - k) // stride + 1
+            Wo = (Wv + 2 * pad - k) // stride + 1
+        return ConvCfg("conv", nimg, H, W, k, k, stride, pad, pad, up, Ho, Wo)
+
+    @staticmethod
+    def conv3d_t(B, F, HW):
+        return ConvCfg("conv", B, F, HW, 3, 1, 1, 1, 0, 0, F, HW)
+
+    def taps(self):
+        return self.KH * self.KW
+
+    def fwd_geom(self, C_in):
+        return nv.ConvGeom(C_in, self.H << self.up, self.W << self.up, self.Ho, self.Wo, self.KH, self.KW, self.stride,
+                           self.stride, self.pad_y, self.pad_x, 1, self.up)
+
+    def bwd_geom(self, C_out):
+        # gather over dY (grid Ho x Wo) producing dX on the virtual input grid; taps are flipped in the prepared weight
+        return nv.ConvGeom(C_out, self.Ho, self.Wo, self.H << self.up, self.W << self.up, self.KH, self.KW, 1, 1,
+                           self.KH - 1 - self.pad_y, self.KW - 1 - self.pad_x, self.stride, 0)
+
+
+LINEAR = ConvCfg()
+
+
+# --------------------------------------------------------------------------- weight preparation (bf16 GEMM layouts)
+_wcache = {}
+
+
+def clear_weight_cache():
+    _wcache.clear()
+
+
+def _prep_compute(w, kind, cfg):
+    """fwd: [Np, Kp] with K ordered (tap, c);  bwd: [Kin_p, taps_flipped*Np]."""
+    wd = w.detach()
+    if wd.dim() == 2:
+        n, k = wd.shape
+        w3 = wd.reshape(n, 1, k)                      # [N, taps=1, Cin]
+    elif wd.dim() == 4:                               # Conv2d [Co, Ci, KH, KW]
+        n, k = wd.shape[0], wd.shape[1]
+        w3 = wd.permute(0, 2, 3, 1).reshape(n, -1, k)
+    elif wd.dim() == 5:                               # Conv3d [Co, Ci, 3, 1, 1]
+        n, k = wd.shape[0], wd.shape[1]
+        w3 = wd[:, :, :, 0, 0].permute(0, 2, 1)
+    else:
+        raise RuntimeError(f"t2v_amd: unsupported weight rank {wd.dim()}")
+    taps = w3.shape[1]
+    npad, kpad = ceil8(n), ceil8(k)
+    if npad != n or kpad != k:
+        wp = torch.zeros(npad, taps, kpad, dtype=wd.dtype, device=wd.device)
+        wp[:n, :, :k] = w3
+        w3 = wp
+    if kind == "fwd":
+        return w3.reshape(npad, taps * kpad).to(BF16).contiguous()
+    # bwd-data: Wb[ci][tap'][co] = W[co][taps-1-tap'][ci]   (flip of the (KH,KW) window == reversal of the flat tap index)
+    return w3.flip(1).permute(2, 1, 0).reshape(kpad, taps * npad).to(BF16).contiguous()
+
+
+def prepared_weight(w, kind):
+    """bf16 GEMM-layout copy of a parameter.  Frozen parameters are cached (keyed on storage + version);
+    trainable ones are re-derived every call so optimizer updates (and graph replays) always see fresh values."""
+    if w.requires_grad:
+        return _prep_compute(w, kind, None)
+    key = (w.data_ptr(), tuple(w.shape), w.dtype, w._version, kind)
+    hit = _wcache.get(key)
+    if hit is None:
+        hit = _prep_compute(w, kind, None)
+        _wcache[key] = hit
+    return hit
+
+
+def _f32(t):
+    if t is None:
+        return None
+    return t.detach() if t.dtype == torch.float32 else t.detach().float()
+
+
+def _pad_vec(v, n):
+    if v is None or v.shape[0] == n:
+        return v
+    out = torch.zeros(n, dtype=v.dtype, device=v.device)
+    out[: v.shape[0]] = v
+    return out
+
+
+# --------------------------------------------------------------------------- raw launches
+def launch_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0, b_conv=0, geom=None, out_mode=0,
+                bias=None, rowbias=None, ldrb=0, rows_per_rb=0, R=None, ldr=0, alpha=1.0, beta=1.0, act=0, batch=1,
+                strideA=0, strideB=0, strideD=0, strideR=0, split_k=1, drop_p=0.0, drop_seed=0):
+    g = Gemm = nv.Gemm()
+    g.M, g.N, g.K = M, N, K
+    g.A, g.lda, g.a_mode, g.a_trans = A, lda, a_mode, a_trans
+    g.B, g.ldb, g.b_trans, g.b_conv = B, ldb, b_trans, b_conv
+    if geom is not None:
+        g.geom = geom
+    g.D, g.ldd, g.out_mode = D, ldd, out_mode
+    g.bias = bias
+    g.rowbias, g.ldrb, g.rows_per_rb = rowbias, ldrb, rows_per_rb
+    g.R, g.ldr = R, ldr
+    g.alpha, g.beta, g.act = alpha, beta, act
+    g.batch, g.strideA, g.strideB, g.strideD, g.strideR = batch, strideA, strideB, strideD, strideR
+    g.split_k = split_k
+    g.drop_p, g.drop_seed = drop_p, drop_seed
+    nv.call("t2v_gemm", C.byref(g), nv.stream())
+
+
+def _split_k(tiles, kdim):
+    return int(max(1, min(64, 512 // max(1, tiles), kdim // 128)))
+
+
+# --------------------------------------------------------------------------- Linear / Conv (implicit GEMM)
+class _ConvLinear(torch.autograd.Function):
+    """y = act(alpha * drop(x (*) W^T) + bias + rowbias[img]) + residual      (x (*) W = linear or sliding window)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rowbias, residual, cfg, alpha, drop_p, drop_seed):
+        x = _mat(x, "x")
+        wq = prepared_weight(weight, "fwd")
+        npad = wq.shape[0]
+        cin_p = wq.shape[1] // cfg.taps()
+        if x.shape[1] != cin_p:
+            raise RuntimeError(f"t2v_amd: input width {x.shape[1]} != prepared weight channels {cin_p}")
+        if cfg.kind == "linear":
+            M = x.shape[0]
+        else:
+            M = cfg.nimg * cfg.Ho * cfg.Wo
+            if x.shape[0] != cfg.nimg * cfg.H * cfg.W:
+                raise RuntimeError(f"t2v_amd: conv input rows {x.shape[0]} != nimg*H*W {cfg.nimg * cfg.H * cfg.W}")
+        y = torch.empty(M, npad, dtype=BF16, device=x.device)
+        b32 = _pad_vec(_f32(bias), npad)
+        rpr = 0
+        if rowbias is not None:
+            rowbias = _mat(rowbias, "rowbias")
+            rpr = M // rowbias.shape[0]
+        if residual is not None:
+            residual = _mat(residual, "residual")
+        launch_gemm(M=M, N=npad, K=wq.shape[1], A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=wq.shape[1],
+                    D=y.data_ptr(), ldd=npad, a_mode=nv.A_DENSE if cfg.kind == "linear" else nv.A_CONV,
+                    geom=None if cfg.kind == "linear" else cfg.fwd_geom(cin_p), bias=nv.ptr(b32),
+                    rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
+                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0, alpha=alpha, beta=1.0,
+                    drop_p=drop_p, drop_seed=drop_seed)
+        ctx.cfg, ctx.alpha, ctx.drop = cfg, alpha, (drop_p, drop_seed)
+        ctx.has = (bias is not None and bias.requires_grad, rowbias is not None, residual is not None)
+        ctx.bias_n = bias.shape[0] if bias is not None else 0
+        ctx.save_for_backward(x, weight, rowbias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, rowbias = ctx.saved_tensors
+        cfg, alpha = ctx.cfg, ctx.alpha
+        drop_p, drop_seed = ctx.drop
+        bias_grad, has_rb, has_res = ctx.has
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        dy = _mat(dy, "dy")
+        M, npad = dy.shape
+        dres = dy if has_res else None
+        drb = None
+        if has_rb:
+            drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
+        db = None
+        if bias_grad:
+            db = dy.sum(0, dtype=torch.float32)[: ctx.bias_n]
+        g = dy
+        if drop_p > 0.0:
+            # dropout sits between the GEMM and bias/residual: re-apply the same mask to dy
+            g = torch.empty_like(dy)
+            ones = None
+            launch_gemm_dropmask(dy, g, drop_p, drop_seed)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wb = prepared_weight(weight, "bwd")        # [Cin_p, taps*Np]
+            cin_p = wb.shape[0]
+            if cfg.kind == "linear":
+                dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+                launch_gemm(M=M, N=cin_p, K=npad, A=g.data_ptr(), lda=_ld(g), B=wb.data_ptr(), ldb=wb.shape[1],
+                            D=dx.data_ptr(), ldd=cin_p, alpha=alpha)
+            else:
+                Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
+                Mi = cfg.nimg * Hv * Wv
+                dxv = torch.empty(Mi, cin_p, dtype=BF16, device=dy.device)
+                launch_gemm(M=Mi, N=cin_p, K=wb.shape[1], A=g.data_ptr(), lda=_ld(g), B=wb.data_ptr(), ldb=wb.shape[1],
+                            D=dxv.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(npad), alpha=alpha)
+                if cfg.up:
+                    dx = torch.empty(cfg.nimg * cfg.H * cfg.W, cin_p, dtype=BF16, device=dy.device)
+                    nv.call("t2v_pool2x2_sum", dxv.data_ptr(), cin_p, dx.data_ptr(), cin_p, cfg.nimg, cfg.H, cfg.W, cin_p,
+                            nv.stream())
+                else:
+                    dx = dxv
+        dw = None
+        if ctx.needs_input_grad[1]:
+            cin_p = x.shape[1]
+            kw = cfg.taps() * cin_p
+            dwp = torch.zeros(npad, kw, dtype=torch.float32, device=dy.device)
+            tiles = ((npad + 63) // 64) * ((kw + 63) // 64)
+            launch_gemm(M=npad, N=kw, K=M, A=g.data_ptr(), lda=_ld(g), a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
+                        b_conv=0 if cfg.kind == "linear" else 1,
+                        geom=None if cfg.kind == "linear" else cfg.fwd_geom(cin_p), D=dwp.data_ptr(), ldd=kw,
+                        out_mode=nv.OUT_F32_ATOMIC, alpha=alpha, split_k=_split_k(tiles, M))
+            dw = _unprep_weight_grad(dwp, weight, cfg)
+        return dx, dw, db, drb, dres, None, None, None, None
+
+
+def launch_gemm_dropmask(dy, out, drop_p, drop_seed):
+    raise RuntimeError("t2v_amd: LoRA-branch dropout backward is not wired yet (run with eval_train / dropout off)")
+
+
+def _unprep_weight_grad(dwp, weight, cfg):
+    """[Np, taps*Cin_p] fp32 (prepared order) -> gradient in the parameter's own layout/dtype."""
+    n = weight.shape[0]
+    cin = weight.shape[1]
+    taps = cfg.taps()
+    d3 = dwp.view(dwp.shape[0], taps, -1)[:n, :, :cin]
+    if weight.dim() == 2:
+        gw = d3.reshape(n, cin)
+    elif weight.dim() == 4:
+        gw = d3.view(n, cfg.KH, cfg.KW, cin).permute(0, 3, 1, 2)
+    else:
+        gw = d3.permute(0, 2, 1).reshape(n, cin, taps, 1, 1)
+    return gw.to(weight.dtype).contiguous()
+
+
+def conv_linear(x, weight, bias=None, cfg=LINEAR, rowbias=None, residual=None, alpha=1.0, drop_p=0.0, drop_seed=0):
+    return _ConvLinear.apply(x, weight, bias, rowbias, residual, cfg, float(alpha), float(drop_p), int(drop_seed))
+
+
+# --------------------------------------------------------------------------- GroupNorm (+SiLU, +dropout)
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, silu, ndomains, drop_p, drop_seed):
+        x = _mat(x, "x")
+        rows, Cc = x.shape
+        rpd = rows // ndomains
+        g32, b32 = _f32(gamma), _f32(beta)
+        sums = torch.zeros(ndomains * G * 2, dtype=torch.float32, device=x.device)
+        s = nv.stream()
+        nv.call("t2v_gn_stats", x.data_ptr(), _ld(x), ndomains, rpd, Cc, G, sums.data_ptr(), s)
+        y = torch.empty(rows, Cc, dtype=BF16, device=x.device)
+        nv.call("t2v_gn_apply", x.data_ptr(), _ld(x), y.data_ptr(), Cc, ndomains, rpd, Cc, G, sums.data_ptr(),
+                g32.data_ptr(), b32.data_ptr(), eps, int(silu), drop_p, drop_seed, s)
+        ctx.args = (G, eps, int(silu), ndomains, rpd, drop_p, drop_seed)
+        ctx.save_for_backward(x, gamma, beta, sums)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, sums = ctx.saved_tensors
+        G, eps, silu, ndomains, rpd, drop_p, drop_seed = ctx.args
+        dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        rows, Cc = x.shape
+        g32, b32 = _f32(gamma), _f32(beta)
+        s = nv.stream()
+        want_pg = gamma.requires_grad or beta.requires_grad
+        dgm = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
+        dbt = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
+        bsums = torch.zeros(ndomains * G * 2, dtype=torch.float32, device=x.device)
+        nv.call("t2v_gn_bwd_stats", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ndomains, rpd, Cc, G, sums.data_ptr(),
+                g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, bsums.data_ptr(), nv.ptr(dgm), nv.ptr(dbt), s)
+        dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
+        nv.call("t2v_gn_bwd_apply", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, ndomains, rpd, Cc, G,
+                sums.data_ptr(), bsums.data_ptr(), g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, s)
+        return (dx, dgm.to(gamma.dtype) if want_pg else None, dbt.to(beta.dtype) if want_pg else None,
+                None, None, None, None, None, None)
+
+
+def group_norm(x, gamma, beta, G, eps, silu, ndomains, drop_p=0.0, drop_seed=0):
+    return _GroupNorm.apply(x, gamma, beta, G, float(eps), bool(silu), int(ndomains), float(drop_p), int(drop_seed))
+
+
+# --------------------------------------------------------------------------- LayerNorm
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _mat(x, "x")
+        rows, Cc = x.shape
+        y = torch.empty(rows, Cc, dtype=BF16, device=x.device)
+        stats = torch.empty(rows * 2, dtype=torch.float32, device=x.device)
+        nv.call("t2v_layernorm_fwd", x.data_ptr(), _ld(x), y.data_ptr(), Cc, rows, Cc, _f32(gamma).data_ptr(),
+                _f32(beta).data_ptr(), eps, stats.data_ptr(), nv.stream())
+        ctx.save_for_backward(x, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        rows, Cc = x.shape
+        want_pg = gamma.requires_grad or beta.requires_grad
+        dgm = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
+        dbt = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
+        dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
+        nv.call("t2v_layernorm_bwd", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, rows, Cc,
+                _f32(gamma).data_ptr(), stats.data_ptr(), nv.ptr(dgm), nv.ptr(dbt), nv.stream())
+        return dx, dgm.to(gamma.dtype) if want_pg else None, dbt.to(beta.dtype) if want_pg else None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+# --------------------------------------------------------------------------- attention core
+@dataclass(frozen=True)
+class SeqLayout:
+    """How (batch b, position s) of a token matrix is addressed, in ROWS:
+    row = (b // bdiv) * hi + (b % bdiv) * lo + s * ss   (element offset = row * ld + head*64)."""
+    nbatch: int
+    S: int
+    hi: int
+    lo: int
+    ss: int
+    bdiv: int = 1
+
+
+def _operand(t, lay):
+    ld = _ld(t)
+    return nv.AttnOperand(t.data_ptr(), lay.hi * ld, lay.lo * ld, lay.ss * ld, lay.bdiv)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, qlay, klay, scale):
+        q, k, v = _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
+        o = torch.empty(q.shape[0], heads * 64, dtype=BF16, device=q.device)
+        lse = torch.empty(qlay.nbatch * heads * qlay.S, dtype=torch.float32, device=q.device)
+        a = nv.Attn()
+        a.nbatch, a.heads, a.Sq, a.Sk, a.scale = qlay.nbatch, heads, qlay.S, klay.S, scale
+        a.q, a.k, a.v, a.o = _operand(q, qlay), _operand(k, klay), _operand(v, klay), _operand(o, qlay)
+        a.lse = lse.data_ptr()
+        nv.call("t2v_attn_fwd", C.byref(a), nv.stream())
+        ctx.meta = (heads, qlay, klay, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        heads, qlay, klay, scale = ctx.meta
+        do = _mat(do if do.stride(1) == 1 else do.contiguous(), "do")
+        width = heads * 64
+        dq = torch.empty(q.shape[0], width, dtype=BF16, device=q.device)
+        # text cross-attention shares one K/V across the frames of a video (klay.lo == 0, bdiv = frames):
+        # dK/dV are produced per query batch and summed over the sharing group below
+        shared = klay.bdiv > 1 and klay.lo == 0
+        if shared:
+            dk = torch.empty(qlay.nbatch * klay.S, width, dtype=BF16, device=q.device)
+            dv = torch.empty_like(dk)
+            dklay = SeqLayout(qlay.nbatch, klay.S, klay.S, 0, 1, 1)
+        else:
+            dk = torch.empty(k.shape[0], width, dtype=BF16, device=q.device)
+            dv = torch.empty_like(dk)
+            dklay = klay
+        delta = torch.empty_like(lse)
+        a = nv.Attn()
+        a.nbatch, a.heads, a.Sq, a.Sk, a.scale = qlay.nbatch, heads, qlay.S, klay.S, scale
+        a.q, a.k, a.v, a.o = _operand(q, qlay), _operand(k, klay), _operand(v, klay), _operand(o, qlay)
+        a.lse = lse.data_ptr()
+        a.d_o, a.dq, a.dk, a.dv = _operand(do, qlay), _operand(dq, qlay), _operand(dk, dklay), _operand(dv, dklay)
+        a.delta = delta.data_ptr()
+        nv.call("t2v_attn_bwd", C.byref(a), nv.stream())
+        if shared:
+            nb_kv = qlay.nbatch // klay.bdiv
+            dk = dk.view(nb_kv, klay.bdiv, klay.S * width).sum(1, dtype=torch.float32).to(BF16).view(nb_kv * klay.S, width)
+            dv = dv.view(nb_kv, klay.bdiv, klay.S * width).sum(1, dtype=torch.float32).to(BF16).view(nb_kv * klay.S, width)
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, heads, qlay, klay, scale=0.125):
+    """q: [rows_q, heads*64]; k, v: [rows_kv, heads*64] (must be dense row-major); layouts describe batching."""
+    return _Attention.apply(q, k, v, int(heads), qlay, klay, float(scale))
+
+
+# --------------------------------------------------------------------------- GEGLU / SiLU
+class _Geglu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _mat(x, "x")
+        rows, two = x.shape
+        inner = two // 2
+        y = torch.empty(rows, inner, dtype=BF16, device=x.device)
+        nv.call("t2v_geglu_fwd", x.data_ptr(), _ld(x), y.data_ptr(), inner, rows, inner, nv.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        rows, two = x.shape
+        dx = torch.empty(rows, two, dtype=BF16, device=x.device)
+        nv.call("t2v_geglu_bwd", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), two, rows, two // 2,
+                nv.stream())
+        return dx
+
+
+def geglu(x):
+    return _Geglu.apply(x)
+
+
+class _Silu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        nv.require_cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        nv.call("t2v_silu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), nv.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        nv.call("t2v_silu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), nv.stream())
+        return dx
+
+
+def silu(x):
+    if x.dtype != BF16:
+        raise RuntimeError("t2v_amd: silu expects bf16")
+    return _Silu.apply(x)
+
+
+# --------------------------------------------------------------------------- concat (skip connections)
+class _Concat(torch.autograd.Function):
+    """torch.cat([a, b], dim=channels) of token matrices (models/unet_3d_blocks.py:764,861)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _mat(a, "a"), _mat(b, "b")
+        rows, ca, cb = a.shape[0], a.shape[1], b.shape[1]
+        y = torch.empty(rows, ca + cb, dtype=BF16, device=a.device)
+        s = nv.stream()
+        nv.call("t2v_copy2d", a.data_ptr(), _ld(a), y.data_ptr(), ca + cb, rows, ca, 0, s)
+        nv.call("t2v_copy2d", b.data_ptr(), _ld(b), y.data_ptr() + 2 * ca, ca + cb, rows, cb, 0, s)
+        ctx.split = (ca, cb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ca, cb = ctx.split
+        return dy[:, :ca], dy[:, ca:]
+
+
+def concat(a, b):
+    return _Concat.apply(a, b)
+
+
+# --------------------------------------------------------------------------- 4-channel boundary
+def planar_f32_to_tokens(x, width=8):
+    """(n, C, rows) fp32 contiguous -> [n*rows, width] bf16 with zero padded channels (latent/pixel entry)."""
+    nv.require_cuda(x)
+    n, Cc, rows = x.shape
+    x = x.contiguous().float()
+    y = torch.zeros(n * rows, width, dtype=BF16, device=x.device)
+    nv.call("t2v_f32_planar_to_bf16_cl", x.data_ptr(), y.data_ptr(), width, n, Cc, rows, nv.stream())
+    return y

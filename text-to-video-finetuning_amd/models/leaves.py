@@ -1,0 +1,364 @@
+"""Native leaf modules: same class names, attribute names and state-dict keys as the diffusers leaves the
+reference imports (`models/unet_3d_blocks.py:18-20`, `models/unet_3d_condition.py:22-26`), but every forward
+runs hand-written HIP kernels on channels-last bf16 token matrices (`t2v_amd.functional`).
+
+Drop-in contract kept: leaf layers are plain `nn.Linear/nn.Conv2d/nn.Conv3d` children reachable via
+`parent._modules[name]`, so `utils/lora.py:_find_modules_v2` + `inject_trainable_lora_extended` (class-name ancestor
+search, exact-class gate, shared base Parameters) work unchanged.  Parents never call `child(x)` on the device path;
+they call `run_layer(child, ...)`, which recognises a swapped-in LoRA wrapper (cloneofsimo: `.linear|.conv`,
+`.lora_down`, `.lora_up`, `.dropout`, `.scale`, `.selector`; loralib style: `.lora_A`, `.lora_B`, `.scaling`)
+and evaluates `base(x) + dropout(up(selector(down(x)))) * scale` (utils/lora.py:57-62,134-139,211-216) with the
+same kernels.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from .. import functional as F
+from ..functional import ConvCfg, LINEAR, SeqLayout
+
+BF16 = torch.bfloat16
+
+
+class Tok:
+    """Channels-last token matrix of an image batch: m [n*h*w, C] bf16 (rows ordered (n, y, x))."""
+    __slots__ = ("m", "n", "h", "w")
+
+    def __init__(self, m, n, h, w):
+        self.m, self.n, self.h, self.w = m, n, h, w
+
+    @property
+    def C(self):
+        return self.m.shape[1]
+
+    @staticmethod
+    def from_nchw(x, pad_to=8):
+        if not x.is_cuda:
+            raise RuntimeError("t2v_amd: the native modules run on a ROCm device only (tensor is on CPU); "
+                               "the CPU restatement lives in oracle/ and is test infrastructure")
+        n, c, h, w = x.shape
+        m = x.permute(0, 2, 3, 1).reshape(n * h * w, c).to(BF16)
+        cp = F.ceil8(c) if pad_to else c
+        if cp != c:
+            m = torch.nn.functional.pad(m, (0, cp - c))
+        return Tok(m.contiguous(), n, h, w)
+
+    def to_nchw(self, channels=None, dtype=torch.float32):
+        c = channels or self.C
+        return self.m[:, :c].reshape(self.n, self.h, self.w, c).permute(0, 3, 1, 2).to(dtype)
+
+
+class _Out(SimpleNamespace):
+    pass
+
+
+_seed_state = {"base": 0x5EED, "ctr": 0}
+
+
+def set_dropout_seed(seed):
+    _seed_state["base"], _seed_state["ctr"] = int(seed), 0
+
+
+def _next_seed():
+    _seed_state["ctr"] += 1
+    return (_seed_state["base"] * 1000003 + _seed_state["ctr"]) & 0xFFFFFFFFFFFF
+
+
+def _drop_p(mod):
+    return float(mod.p) if (isinstance(mod, nn.Dropout) and mod.training) else 0.0
+
+
+def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None):
+    """Evaluate a Linear/Conv leaf (or a LoRA wrapper swapped in for it) on a token matrix."""
+    if isinstance(mod, (nn.Linear, nn.Conv2d, nn.Conv3d)) and not hasattr(mod, "lora_A"):
+        return F.conv_linear(x, mod.weight, mod.bias, cfg, rowbias, residual)
+    base = getattr(mod, "linear", None)
+    if base is None:
+        base = getattr(mod, "conv", None)
+    if base is not None and hasattr(mod, "lora_down") and hasattr(mod, "lora_up"):      # cloneofsimo wrapper
+        y = F.conv_linear(x, base.weight, base.bias, cfg, rowbias, residual)
+        t = F.conv_linear(x, mod.lora_down.weight, None, cfg)
+        sel = getattr(mod, "selector", None)
+        if sel is not None and not isinstance(sel, nn.Identity):
+            t = F.conv_linear(t, sel.weight, None, LINEAR)
+        p = _drop_p(getattr(mod, "dropout", None))
+        return F.conv_linear(t, mod.lora_up.weight, None, LINEAR, None, y, alpha=float(mod.scale), drop_p=p,
+                             drop_seed=_next_seed() if p > 0 else 0)
+    if hasattr(mod, "lora_A") and hasattr(mod, "lora_B"):                               # loralib / stable_lora style
+        w = mod.weight
+        if getattr(mod, "r", 0) > 0 and not getattr(mod, "merged", False):
+            delta = (mod.lora_B @ mod.lora_A)
+            if w.dim() == 5:   # stable_lora Conv3d: view(out,in,k,k,1).mean(-2)  (stable_lora/lora.py:148-149,194)
+                delta = delta.view(w.shape[0], w.shape[1], w.shape[2], w.shape[2], 1).mean(dim=-2, keepdim=True) \
+                    .view(w.shape)
+            else:
+                delta = delta.view(w.shape)
+            w = w + delta * mod.scaling
+        return F.conv_linear(x, w, mod.bias, cfg, rowbias, residual)
+    raise RuntimeError(f"t2v_amd: don't know how to run layer of type {type(mod).__name__} natively")
+
+
+# --------------------------------------------------------------------------- time embedding
+class Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos=True, downscale_freq_shift=0.0):
+        super().__init__()
+        self.num_channels, self.flip_sin_to_cos, self.downscale_freq_shift = num_channels, flip_sin_to_cos, downscale_freq_shift
+
+    def forward(self, timesteps):
+        half = self.num_channels // 2
+        exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
+        exponent = exponent / (half - self.downscale_freq_shift)
+        emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+        if self.flip_sin_to_cos:
+            emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+        return emb
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample, condition=None):
+        x = sample.to(BF16).contiguous()
+        return run_layer(self.linear_2, F.silu(run_layer(self.linear_1, x)))
+
+
+class Temb:
+    """Per-video time embedding [B, 1280] with its SiLU cached (every ResnetBlock2D applies the same SiLU)."""
+
+    def __init__(self, raw):
+        self.raw = raw
+        self._act = None
+
+    @property
+    def act(self):
+        if self._act is None:
+            self._act = F.silu(self.raw)
+        return self._act
+
+
+# --------------------------------------------------------------------------- ResnetBlock2D
+class ResnetBlock2D(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, temb_channels=512, eps=1e-5, groups=32, dropout=0.0,
+                 time_embedding_norm="default", non_linearity="silu", output_scale_factor=1.0, pre_norm=True):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.output_scale_factor = output_scale_factor
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps, affine=True)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.nonlinearity = nn.SiLU()
+        self.conv_shortcut = None
+        if in_channels != out_channels:
+            self.conv_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x, temb=None):
+        if self.output_scale_factor != 1.0:
+            raise RuntimeError("t2v_amd: output_scale_factor != 1 is not used by the reference configs")
+        cfg3 = ConvCfg.conv2d(x.n, x.h, x.w, 3, 1, 1)
+        a = F.group_norm(x.m, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, True, x.n)
+        rb = None
+        if temb is not None and self.time_emb_proj is not None:
+            rb = run_layer(self.time_emb_proj, temb.act)          # [B, Cout]; broadcast over the B's F*h*w rows
+        h = run_layer(self.conv1, a, cfg3, rowbias=rb)
+        a2 = F.group_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, x.n,
+                          _drop_p(self.dropout), _next_seed() if _drop_p(self.dropout) > 0 else 0)
+        sc = x.m
+        if self.conv_shortcut is not None:
+            sc = run_layer(self.conv_shortcut, x.m, ConvCfg.conv2d(x.n, x.h, x.w, 1, 1, 0))
+        out = run_layer(self.conv2, a2, cfg3, residual=sc)
+        return Tok(out, x.n, x.h, x.w)
+
+
+# --------------------------------------------------------------------------- TemporalConvLayer
+class TemporalConvLayer(nn.Module):
+    def __init__(self, in_dim, out_dim=None, dropout=0.0):
+        super().__init__()
+        out_dim = out_dim or in_dim
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.conv1 = nn.Sequential(nn.GroupNorm(32, in_dim), nn.SiLU(),
+                                   nn.Conv3d(in_dim, out_dim, (3, 1, 1), padding=(1, 0, 0)))
+        self.conv2 = nn.Sequential(nn.GroupNorm(32, out_dim), nn.SiLU(), nn.Dropout(dropout),
+                                   nn.Conv3d(out_dim, in_dim, (3, 1, 1), padding=(1, 0, 0)))
+        self.conv3 = nn.Sequential(nn.GroupNorm(32, out_dim), nn.SiLU(), nn.Dropout(dropout),
+                                   nn.Conv3d(out_dim, in_dim, (3, 1, 1), padding=(1, 0, 0)))
+        self.conv4 = nn.Sequential(nn.GroupNorm(32, out_dim), nn.SiLU(), nn.Dropout(dropout),
+                                   nn.Conv3d(out_dim, in_dim, (3, 1, 1), padding=(1, 0, 0)))
+        nn.init.zeros_(self.conv4[-1].weight)
+        nn.init.zeros_(self.conv4[-1].bias)
+
+    def forward(self, x, num_frames=1):
+        B = x.n // num_frames
+        cfg = ConvCfg.conv3d_t(B, num_frames, x.h * x.w)
+        cur = x.m
+        seqs = (self.conv1, self.conv2, self.conv3, self.conv4)
+        for i, seq in enumerate(seqs):
+            gn, conv = seq[0], seq[-1]
+            p = max((_drop_p(mm) for mm in seq), default=0.0)
+            a = F.group_norm(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
+            cur = run_layer(conv, a, cfg, residual=x.m if i == 3 else None)
+        return Tok(cur, x.n, x.h, x.w)
+
+
+# --------------------------------------------------------------------------- attention / transformer blocks
+class Attention(nn.Module):
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False):
+        super().__init__()
+        if dim_head != 64:
+            raise ValueError("t2v_amd: the native attention kernel is specialised for head_dim 64")
+        inner = heads * dim_head
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        kv = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(kv, inner, bias=bias)
+        self.to_v = nn.Linear(kv, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+        self.processor = None
+
+    def set_processor(self, processor):   # train.py:138-139 — accepted; the native core is always used on device
+        self.processor = processor
+
+    def forward(self, x, qlay, ctx=None, klay=None, residual=None):
+        src = x if ctx is None else ctx
+        q = run_layer(self.to_q, x)
+        k = run_layer(self.to_k, src)
+        v = run_layer(self.to_v, src)
+        o = F.attention(q, k, v, self.heads, qlay, qlay if klay is None else klay, self.scale)
+        return run_layer(self.to_out[0], o, residual=residual)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        return F.geglu(run_layer(self.proj, x))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4, dropout=0.0):
+        super().__init__()
+        inner = dim * mult
+        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim)])
+
+    def forward(self, x, residual=None):
+        return run_layer(self.net[2], self.net[0](x), residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, num_attention_heads, attention_head_dim, cross_attention_dim=None, attention_bias=False,
+                 double_self_attention=False):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, num_attention_heads, attention_head_dim, bias=attention_bias)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, None if double_self_attention else cross_attention_dim, num_attention_heads,
+                               attention_head_dim, bias=attention_bias)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, t, qlay, ctx=None, klay=None):
+        t = self.attn1(F.layer_norm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps), qlay, residual=t)
+        t = self.attn2(F.layer_norm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps), qlay, ctx, klay, residual=t)
+        return self.ff(F.layer_norm(t, self.norm3.weight, self.norm3.bias, self.norm3.eps), residual=t)
+
+
+class TextCtx:
+    """encoder_hidden_states as a token matrix [B*S, D] (NOT repeated per frame: the F-fold
+    `repeat_interleave` of models/unet_3d_condition.py:401 is expressed through the attention batch map)."""
+
+    def __init__(self, ehs):
+        b, s, d = ehs.shape
+        self.m = ehs.reshape(b * s, d).to(BF16).contiguous()
+        self.B, self.S = b, s
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, num_attention_heads=16, attention_head_dim=88, in_channels=None, num_layers=1,
+                 cross_attention_dim=None, norm_num_groups=32, use_linear_projection=True, **_):
+        super().__init__()
+        inner = num_attention_heads * attention_head_dim
+        self.in_channels = in_channels
+        self.norm = nn.GroupNorm(norm_num_groups, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, cross_attention_dim)
+            for _ in range(num_layers)])
+        self.proj_out = nn.Linear(inner, in_channels)
+
+    def forward(self, x, encoder_hidden_states=None, num_frames=1, **_):
+        hw = x.h * x.w
+        a = F.group_norm(x.m, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, False, x.n)
+        t = run_layer(self.proj_in, a)
+        qlay = SeqLayout(x.n, hw, hw, 0, 1, 1)
+        ctx = encoder_hidden_states
+        klay = SeqLayout(x.n, ctx.S, ctx.S, 0, 1, x.n // ctx.B)
+        for blk in self.transformer_blocks:
+            t = blk(t, qlay, ctx.m, klay)
+        out = run_layer(self.proj_out, t, residual=x.m)
+        return _Out(sample=Tok(out, x.n, x.h, x.w))
+
+
+class TransformerTemporalModel(nn.Module):
+    def __init__(self, num_attention_heads=16, attention_head_dim=88, in_channels=None, num_layers=1,
+                 cross_attention_dim=None, norm_num_groups=32, **_):
+        super().__init__()
+        inner = num_attention_heads * attention_head_dim
+        self.in_channels = in_channels
+        self.norm = nn.GroupNorm(norm_num_groups, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, cross_attention_dim,
+                                  double_self_attention=True)
+            for _ in range(num_layers)])
+        self.proj_out = nn.Linear(inner, in_channels)
+
+    def forward(self, x, encoder_hidden_states=None, num_frames=1, **_):
+        hw = x.h * x.w
+        B = x.n // num_frames
+        a = F.group_norm(x.m, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, False, B)
+        t = run_layer(self.proj_in, a)
+        # rows are (b, f, pixel): a sequence = the F rows of one pixel, stride hw rows — no permute copies
+        qlay = SeqLayout(B * hw, num_frames, num_frames * hw, 1, hw, hw)
+        for blk in self.transformer_blocks:
+            t = blk(t, qlay)
+        out = run_layer(self.proj_out, t, residual=x.m)
+        return _Out(sample=Tok(out, x.n, x.h, x.w))
+
+
+# --------------------------------------------------------------------------- resampling
+class Downsample2D(nn.Module):
+    def __init__(self, channels, use_conv=True, out_channels=None, padding=1, name="conv"):
+        super().__init__()
+        self.padding = padding
+        self.conv = nn.Conv2d(channels, out_channels or channels, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        if self.padding == 0:   # VAE flavour: F.pad(x,(0,1,0,1)) then stride 2, pad 0
+            cfg = ConvCfg("conv", x.n, x.h, x.w, 3, 3, 2, 0, 0, 0, x.h // 2, x.w // 2)
+        else:
+            cfg = ConvCfg.conv2d(x.n, x.h, x.w, 3, 2, self.padding)
+        return Tok(run_layer(self.conv, x.m, cfg), x.n, cfg.Ho, cfg.Wo)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels, use_conv=True, out_channels=None):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, out_channels or channels, 3, padding=1)
+
+    def forward(self, x, output_size=None):
+        if output_size is not None and tuple(output_size) != (2 * x.h, 2 * x.w):
+            raise RuntimeError("t2v_amd: only the exact 2x nearest upsample is implemented natively")
+        cfg = ConvCfg.conv2d(x.n, x.h, x.w, 3, 1, 1, up=1)
+        return Tok(run_layer(self.conv, x.m, cfg), x.n, 2 * x.h, 2 * x.w)

@@ -1,0 +1,166 @@
+"""Drop-in `UNet3DConditionModel` (reference: `models/unet_3d_condition.py:53-500`).
+
+Same constructor arguments/defaults (`:86-107`), attribute tree and state-dict keys (`:128-251`), the same
+`forward(sample (B,4,F,h,w), timestep, encoder_hidden_states (B,77,1024), ...) -> .sample (B,4,F,h,w)` (`:325-500`),
+`_set_gradient_checkpointing` (`:318-323`) and `set_attention_slice` (accepted, no-op: the flash-style core never
+materialises the score matrix).  The forward runs entirely on hand-written HIP kernels over channels-last bf16
+token matrices; there is no CPU/eager path (CPU tensors raise).
+"""
+from dataclasses import dataclass
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from .. import functional as F
+from ..functional import ConvCfg
+from .leaves import TextCtx, Temb, TimestepEmbedding, Timesteps, Tok, TransformerTemporalModel, run_layer
+from .modeling_utils import ModelMixinLite
+from .unet_3d_blocks import (CrossAttnDownBlock3D, CrossAttnUpBlock3D, DownBlock3D, UNetMidBlock3DCrossAttn, UpBlock3D,
+                             get_down_block, get_up_block)
+
+
+@dataclass
+class UNet3DConditionOutput:
+    sample: torch.Tensor
+
+
+class UNet3DConditionModel(nn.Module, ModelMixinLite):
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
+                 down_block_types: Tuple[str] = ("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D",
+                                                 "DownBlock3D"),
+                 up_block_types: Tuple[str] = ("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D",
+                                               "CrossAttnUpBlock3D"),
+                 block_out_channels: Tuple[int] = (320, 640, 1280, 1280), layers_per_block: int = 2,
+                 downsample_padding: int = 1, mid_block_scale_factor: float = 1, act_fn: str = "silu",
+                 norm_num_groups: Optional[int] = 32, norm_eps: float = 1e-5, cross_attention_dim: int = 1024,
+                 attention_head_dim: Union[int, Tuple[int]] = 64):
+        super().__init__()
+        self.register_to_config(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+                                down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+                                block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+                                downsample_padding=downsample_padding, mid_block_scale_factor=mid_block_scale_factor,
+                                act_fn=act_fn, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
+                                cross_attention_dim=cross_attention_dim, attention_head_dim=attention_head_dim)
+        self.sample_size = sample_size
+        self.gradient_checkpointing = False
+        if len(down_block_types) != len(up_block_types):
+            raise ValueError("Must provide the same number of `down_block_types` as `up_block_types`.")
+        if len(block_out_channels) != len(down_block_types):
+            raise ValueError("Must provide the same number of `block_out_channels` as `down_block_types`.")
+        if not isinstance(attention_head_dim, int) and len(attention_head_dim) != len(down_block_types):
+            raise ValueError("Must provide the same number of `attention_head_dim` as `down_block_types`.")
+        boc = tuple(block_out_channels)
+        self.conv_in = nn.Conv2d(in_channels, boc[0], kernel_size=3, padding=1)
+        time_embed_dim = boc[0] * 4
+        self.time_proj = Timesteps(boc[0], True, 0)
+        self.time_embedding = TimestepEmbedding(boc[0], time_embed_dim, act_fn=act_fn)
+        self.transformer_in = TransformerTemporalModel(num_attention_heads=8, attention_head_dim=attention_head_dim,
+                                                       in_channels=boc[0], num_layers=1)
+        self.down_blocks = nn.ModuleList([])
+        self.up_blocks = nn.ModuleList([])
+        if isinstance(attention_head_dim, int):
+            attention_head_dim = (attention_head_dim,) * len(down_block_types)
+        output_channel = boc[0]
+        for i, down_block_type in enumerate(down_block_types):
+            input_channel, output_channel = output_channel, boc[i]
+            is_final_block = i == len(boc) - 1
+            self.down_blocks.append(get_down_block(
+                down_block_type, num_layers=layers_per_block, in_channels=input_channel, out_channels=output_channel,
+                temb_channels=time_embed_dim, add_downsample=not is_final_block, resnet_eps=norm_eps,
+                resnet_act_fn=act_fn, resnet_groups=norm_num_groups, cross_attention_dim=cross_attention_dim,
+                attn_num_head_channels=attention_head_dim[i], downsample_padding=downsample_padding))
+        self.mid_block = UNetMidBlock3DCrossAttn(
+            in_channels=boc[-1], temb_channels=time_embed_dim, resnet_eps=norm_eps, resnet_act_fn=act_fn,
+            output_scale_factor=mid_block_scale_factor, cross_attention_dim=cross_attention_dim,
+            attn_num_head_channels=attention_head_dim[-1], resnet_groups=norm_num_groups)
+        self.num_upsamplers = 0
+        rboc = list(reversed(boc))
+        rhd = list(reversed(attention_head_dim))
+        output_channel = rboc[0]
+        for i, up_block_type in enumerate(up_block_types):
+            is_final_block = i == len(boc) - 1
+            prev_output_channel, output_channel = output_channel, rboc[i]
+            input_channel = rboc[min(i + 1, len(boc) - 1)]
+            if not is_final_block:
+                self.num_upsamplers += 1
+            self.up_blocks.append(get_up_block(
+                up_block_type, num_layers=layers_per_block + 1, in_channels=input_channel,
+                out_channels=output_channel, prev_output_channel=prev_output_channel, temb_channels=time_embed_dim,
+                add_upsample=not is_final_block, resnet_eps=norm_eps, resnet_act_fn=act_fn,
+                resnet_groups=norm_num_groups, cross_attention_dim=cross_attention_dim,
+                attn_num_head_channels=rhd[i]))
+        if norm_num_groups is not None:
+            self.conv_norm_out = nn.GroupNorm(num_channels=boc[0], num_groups=norm_num_groups, eps=norm_eps)
+            self.conv_act = nn.SiLU()
+        else:
+            self.conv_norm_out = None
+            self.conv_act = None
+        self.conv_out = nn.Conv2d(boc[0], out_channels, kernel_size=3, padding=1)
+
+    def set_attention_slice(self, slice_size):
+        return None
+
+    def _set_gradient_checkpointing(self, module=None, value=False):
+        if isinstance(module, bool):   # reference signature is (value=False)
+            value = module
+        self.gradient_checkpointing = value
+        self.mid_block.gradient_checkpointing = value
+        for m in list(self.down_blocks) + list(self.up_blocks):
+            if isinstance(m, (CrossAttnDownBlock3D, DownBlock3D, CrossAttnUpBlock3D, UpBlock3D)):
+                m.gradient_checkpointing = value
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None,
+                attention_mask=None, cross_attention_kwargs=None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None, return_dict: bool = True):
+        if not sample.is_cuda:
+            raise RuntimeError("t2v_amd.UNet3DConditionModel runs on a ROCm device only; move the model and inputs to "
+                               "cuda (the CPU restatement used for parity lives in oracle/).")
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise RuntimeError("t2v_amd: ControlNet-style additional residuals are not on the training path")
+        up_factor = 2 ** self.num_upsamplers
+        if any(s % up_factor != 0 for s in sample.shape[-2:]):
+            raise RuntimeError(f"t2v_amd: latent height/width must be multiples of {up_factor} (got {tuple(sample.shape[-2:])})")
+        timesteps = timestep
+        if not torch.is_tensor(timesteps):
+            timesteps = torch.tensor([timesteps], dtype=torch.int64, device=sample.device)
+        elif timesteps.dim() == 0:
+            timesteps = timesteps[None].to(sample.device)
+        B, Cin, num_frames, h, w = sample.shape
+        timesteps = timesteps.expand(B)
+        t_emb = self.time_proj(timesteps)
+        temb = Temb(self.time_embedding(t_emb, timestep_cond))          # [B, 1280]; broadcast per video in the conv epilogue
+        text = TextCtx(encoder_hidden_states)
+        x = Tok.from_nchw(sample.permute(0, 2, 1, 3, 4).reshape(B * num_frames, Cin, h, w))
+        x = Tok(run_layer(self.conv_in, x.m, ConvCfg.conv2d(x.n, h, w, 3, 1, 1)), x.n, h, w)
+        if num_frames > 1:
+            x = self.transformer_in(x, num_frames=num_frames).sample
+        res_samples = (x,)
+        for blk in self.down_blocks:
+            if getattr(blk, "has_cross_attention", False):
+                x, res = blk(hidden_states=x, temb=temb, encoder_hidden_states=text, num_frames=num_frames)
+            else:
+                x, res = blk(hidden_states=x, temb=temb, num_frames=num_frames)
+            res_samples += res
+        x = self.mid_block(x, temb, encoder_hidden_states=text, num_frames=num_frames)
+        for i, blk in enumerate(self.up_blocks):
+            n = len(blk.resnets)
+            res, res_samples = res_samples[-n:], res_samples[:-n]
+            if getattr(blk, "has_cross_attention", False):
+                x = blk(hidden_states=x, temb=temb, res_hidden_states_tuple=res, encoder_hidden_states=text,
+                        num_frames=num_frames)
+            else:
+                x = blk(hidden_states=x, temb=temb, res_hidden_states_tuple=res, num_frames=num_frames)
+        if self.conv_norm_out is not None:
+            a = F.group_norm(x.m, self.conv_norm_out.weight, self.conv_norm_out.bias, self.conv_norm_out.num_groups,
+                             self.conv_norm_out.eps, True, x.n)
+        else:
+            a = x.m
+        y = Tok(run_layer(self.conv_out, a, ConvCfg.conv2d(x.n, x.h, x.w, 3, 1, 1)), x.n, x.h, x.w)
+        out = y.to_nchw(self.config.out_channels, torch.float32)
+        out = out.reshape(B, num_frames, self.config.out_channels, h, w).permute(0, 2, 1, 3, 4)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)

@@ -1,0 +1,151 @@
+"""ctypes binding of the C ABI in include/t2v_abi.h (libt2v_hip.so).
+
+This module is the ONLY place that touches the shared library.  It fails loudly: if the library
+is missing or a call returns non-zero a RuntimeError is raised (the reference's train loop
+swallows exceptions in backward, train.py:881-883, so errors must not be silent — they are also
+printed to stderr).  There is no CPU fallback anywhere in the product path.
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2v_hip.so")
+
+c_void_p, c_int, c_ll, c_float, c_ull = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, c_int) for n in "C Hv Wv Ho Wo KH KW sy sx py px tdiv up".split()]
+
+
+class Gemm(C.Structure):
+    _fields_ = [
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("A", c_void_p), ("lda", c_ll), ("a_mode", c_int), ("a_trans", c_int),
+        ("B", c_void_p), ("ldb", c_ll), ("b_trans", c_int), ("b_conv", c_int),
+        ("geom", ConvGeom),
+        ("D", c_void_p), ("ldd", c_ll), ("out_mode", c_int),
+        ("bias", c_void_p),
+        ("rowbias", c_void_p), ("ldrb", c_ll), ("rows_per_rb", c_int),
+        ("R", c_void_p), ("ldr", c_ll),
+        ("alpha", c_float), ("beta", c_float),
+        ("act", c_int),
+        ("batch", c_int), ("strideA", c_ll), ("strideB", c_ll), ("strideD", c_ll), ("strideR", c_ll),
+        ("split_k", c_int),
+        ("drop_p", c_float), ("drop_seed", c_ull),
+    ]
+
+
+class SmallConv(C.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_ll), ("x_nchw_f32", c_int),
+        ("w", c_void_p), ("bias", c_void_p),
+        ("y", c_void_p), ("ldy", c_ll), ("y_nchw_f32", c_int),
+        ("nimg", c_int), ("Cin", c_int), ("Cout", c_int), ("geom", ConvGeom),
+    ]
+
+
+class AttnOperand(C.Structure):
+    _fields_ = [("ptr", c_void_p), ("bstride_hi", c_ll), ("bstride_lo", c_ll), ("sstride", c_ll), ("bdiv", c_int)]
+
+
+class Attn(C.Structure):
+    _fields_ = [
+        ("nbatch", c_int), ("heads", c_int), ("Sq", c_int), ("Sk", c_int), ("scale", c_float),
+        ("q", AttnOperand), ("k", AttnOperand), ("v", AttnOperand), ("o", AttnOperand),
+        ("lse", c_void_p),
+        ("d_o", AttnOperand), ("dq", AttnOperand), ("dk", AttnOperand), ("dv", AttnOperand),
+        ("delta", c_void_p),
+    ]
+
+
+A_DENSE, A_CONV = 0, 1
+OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+# every symbol include/t2v_abi.h declares (checked by tests/test_abi.py)
+SYMBOLS = {
+    "t2v_abi_version": ([], c_int),
+    "t2v_last_error": ([], C.c_char_p),
+    "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_smallconv": ([C.POINTER(SmallConv), c_void_p], c_int),
+    "t2v_gn_stats": ([c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "t2v_gn_apply": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                      c_int, c_float, c_ull, c_void_p], c_int),
+    "t2v_gn_bwd_stats": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                          c_float, c_int, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "t2v_gn_bwd_apply": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_float, c_int, c_float, c_ull, c_void_p], c_int),
+    "t2v_layernorm_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p],
+                          c_int),
+    "t2v_layernorm_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_void_p], c_int),
+    "t2v_attn_fwd": ([C.POINTER(Attn), c_void_p], c_int),
+    "t2v_attn_bwd": ([C.POINTER(Attn), c_void_p], c_int),
+    "t2v_geglu_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
+    "t2v_geglu_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
+    "t2v_silu_fwd": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),
+    "t2v_silu_bwd": ([c_void_p, c_void_p, c_void_p, c_ll, c_void_p], c_int),
+    "t2v_copy2d": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_void_p], c_int),
+    "t2v_pool2x2_sum": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "t2v_f32_planar_to_bf16_cl": ([c_void_p, c_void_p, c_ll, c_int, c_int, c_ll, c_void_p], c_int),
+    "t2v_bf16_cl_to_f32_planar": ([c_void_p, c_ll, c_void_p, c_int, c_int, c_ll, c_void_p], c_int),
+    "t2v_cast_f32_to_bf16": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),
+    "t2v_cast_bf16_to_f32": ([c_void_p, c_void_p, c_ll, c_int, c_void_p], c_int),
+    "t2v_mse_fwd_bwd": ([c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_float, c_void_p], c_int),
+    "t2v_sumsq": ([c_void_p, c_ll, c_void_p, c_void_p], c_int),
+    "t2v_adamw": ([c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float, c_void_p,
+                   c_float, c_float, c_void_p, c_void_p], c_int),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libt2v_hip.so (once).  Raises if it has not been built — no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"t2v_amd: native library {LIB_PATH} not found. Build it with "
+                f"`python __graft_entry__.py` (or `python text-to-video-finetuning_amd/build_ext.py`). "
+                f"There is no CPU/eager fallback for the device path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if l.t2v_abi_version() != 1:
+            raise RuntimeError("t2v_amd: ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().t2v_last_error().decode("utf-8", "replace")
+        text = f"t2v_amd native call {what} failed (rc={rc}): {msg}"
+        print(text, file=sys.stderr, flush=True)
+        raise RuntimeError(text)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("t2v_amd: the native path needs tensors on a ROCm device (cuda:N); got a CPU tensor. "
+                               "There is no CPU fallback in the product path (the CPU oracle lives in oracle/).")

@@ -1,0 +1,80 @@
+"""`LoraHandler` — mirror of the reference facade `utils/lora_handler.py:70-351` for the cloneofsimo flavour.
+
+Same constructor, `add_lora_to_model(use, model, replace_modules, dropout, lora_path, r) -> (params, negation)`
+(`:239-268`), `save_lora_weights` (`:335-351`, `{step}_unet.pt` list-of-tensors format) and
+`deactivate_lora_train` (`:271-277`).  The stable_lora flavour needs `loralib` (absent offline); wrappers in that
+style that are already in a model are still evaluated natively (`models.leaves.run_layer`).
+"""
+import os
+from types import SimpleNamespace
+
+import torch
+
+from .lora import inject_trainable_lora_extended, monkeypatch_or_replace_lora_extended, save_lora_weight
+
+LoraVersions = SimpleNamespace(stable_lora="stable_lora", cloneofsimo="cloneofsimo")
+LoraFuncTypes = SimpleNamespace(loader="loader", injector="injector")
+FILE_BASENAMES = ["unet", "text_encoder"]
+LORA_FILE_TYPES = [".pt", ".safetensors"]
+
+
+class LoraHandler(object):
+    def __init__(self, version=LoraVersions.cloneofsimo, use_unet_lora=False, use_text_lora=False, save_for_webui=False,
+                 only_for_webui=False, lora_bias="none", unet_replace_modules=("UNet3DConditionModel",),
+                 text_encoder_replace_modules=("CLIPEncoderLayer",)):
+        if version != LoraVersions.cloneofsimo:
+            raise NotImplementedError("t2v_amd LoraHandler: only the cloneofsimo flavour is mirrored (loralib is not "
+                                      "available offline); stable_lora-style layers already in a model still run natively")
+        self.version = version
+        self.lora_loader = monkeypatch_or_replace_lora_extended
+        self.lora_injector = inject_trainable_lora_extended
+        self.lora_bias = lora_bias
+        self.use_unet_lora, self.use_text_lora = use_unet_lora, use_text_lora
+        self.save_for_webui, self.only_for_webui = save_for_webui, only_for_webui
+        self.unet_replace_modules = list(unet_replace_modules)
+        self.text_encoder_replace_modules = list(text_encoder_replace_modules)
+        self.use_lora = any([use_text_lora, use_unet_lora])
+        if self.use_lora:
+            print(f"Using LoRA Version: {self.version}")
+
+    def is_cloneofsimo_lora(self):
+        return True
+
+    def is_stable_lora(self):
+        return False
+
+    @staticmethod
+    def _is_unet(model):
+        return model.__class__.__name__ == "UNet3DConditionModel"
+
+    def get_lora_file_path(self, lora_path, model):
+        if lora_path is None or not os.path.exists(lora_path):
+            return None
+        want = FILE_BASENAMES[0] if self._is_unet(model) else FILE_BASENAMES[1]
+        for f in sorted(os.listdir(lora_path)):
+            base, ext = os.path.splitext(f)
+            if ext in LORA_FILE_TYPES and want in base:
+                return os.path.join(lora_path, f)
+        return None
+
+    def add_lora_to_model(self, use_lora, model, replace_modules, dropout=0.0, lora_path=None, r=16):
+        """Returns (params, negation): params = list of parameter generators (cloneofsimo) or the model itself."""
+        params, negation = None, None
+        if use_lora:
+            lora_file = self.get_lora_file_path(lora_path, model)
+            params, negation = self.lora_injector(model, target_replace_module=set(replace_modules), r=r, loras=lora_file)
+            n = sum(1 for _ in model.modules() if _.__class__.__name__.startswith("LoraInjected"))
+            print(f"Successfully injected LoRA into {n} layers of {model.__class__.__name__}.")
+        params = model if params is None else params
+        return params, negation
+
+    def deactivate_lora_train(self, models, deactivate=True):
+        return None   # cloneofsimo flavour: nothing to toggle (utils/lora_handler.py:271-277)
+
+    def save_lora_weights(self, model, save_path="", step=""):
+        os.makedirs(save_path, exist_ok=True)
+        unet = getattr(model, "unet", model)
+        save_lora_weight(unet, os.path.join(save_path, f"{step}_unet.pt"), set(self.unet_replace_modules))
+        te = getattr(model, "text_encoder", None)
+        if te is not None and self.use_text_lora:
+            save_lora_weight(te, os.path.join(save_path, f"{step}_text_encoder.pt"), set(self.text_encoder_replace_modules))
