@@ -82,6 +82,18 @@ typedef struct {
   int split_k;
   /* optional dropout on (alpha*acc) BEFORE bias/residual — LoRA branch (utils/lora.py:49,119) */
   float drop_p; unsigned long long drop_seed;
+  /* optional second weight/output block (b_trans=0 only): output columns n >= n_split use rows (n - n_split) of B2 and
+   * are written, scaled by alpha only, to D2[m, n - n_split] — the LoRA down-projection rides in the base layer's launch
+   * (one read of the activations for `linear(x)` and `lora_down(x)`, utils/lora.py:59-60).  n_split <= 0: unused. */
+  const void* B2; long long ldb2; int n_split; void* D2; long long ldd2;
+  /* b_trans=1 only: B is a conv weight stored [r, taps, C] and is read as the flipped-tap transpose
+   * B[n=c, k=(tap', j)] = W[j, taps-1-tap', c]  (backward-data of a LoRA down conv without a transposed copy);
+   * uses geom.C (= r) and geom.KH*geom.KW of the A gather. */
+  int b_tapflip;
+  /* optional caller-owned fp32 scratch (>= M*N*4 bytes): lets the library split K across workgroups for deep-K launches
+   * with few output tiles (partials are accumulated in the scratch, a finalize pass applies the epilogue).
+   * ws_split is internal (set 0). */
+  void* workspace; size_t workspace_bytes; int ws_split;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
 
@@ -99,17 +111,20 @@ int t2v_smallconv(const T2VSmallConv* p, t2v_stream_t stream);
 /* ---- GroupNorm (+SiLU) over channels-last data.  Replaces F.group_norm(+F.silu) of ResnetBlock2D.norm1/2,
  * TemporalConvLayer.conv*[0:2], Transformer2DModel.norm, TransformerTemporalModel.norm, conv_norm_out
  * (models/unet_3d_condition.py:239-243,488-490).  A "domain" = the rows one statistic spans: H*W rows
- * (per-frame norms) or F*H*W rows (5-D temporal norms).  sums: fp32 [ndomains, G, 2] = (sum, sumsq), zeroed by caller. */
+ * (per-frame norms) or F*H*W rows (5-D temporal norms).  sums: fp32 [ndomains, G, 2] = (sum, sumsq), written (not
+ * accumulated).  Statistics are reduced in a fixed order (no atomics): results are bit-reproducible.
+ * workspace: fp32 scratch of t2v_gn_workspace_floats(ndomains, G) elements. */
+long long t2v_gn_workspace_floats(int ndomains, int G);
 int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows_per_domain, int C, int G,
-                 float* sums, t2v_stream_t stream);
+                 float* sums, float* workspace, t2v_stream_t stream);
 int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy, int ndomains, int rows_per_domain, int C, int G,
                  const float* sums, const float* gamma, const float* beta, float eps, int silu,
                  float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
-/* backward: bsums fp32 [ndomains,G,2] = (sum dxh, sum dxh*xh) zeroed by caller; dgamma/dbeta fp32 [C] accumulate (may be NULL) */
+/* backward: bsums fp32 [ndomains,G,2] = (sum dxh, sum dxh*xh), written; dgamma/dbeta fp32 [C] accumulate (may be NULL) */
 int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long lddy, int ndomains, int rows_per_domain,
                      int C, int G, const float* sums, const float* gamma, const float* beta, float eps, int silu,
                      float drop_p, unsigned long long drop_seed,
-                     float* bsums, float* dgamma, float* dbeta, t2v_stream_t stream);
+                     float* bsums, float* workspace, float* dgamma, float* dbeta, t2v_stream_t stream);
 int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
                      int ndomains, int rows_per_domain, int C, int G, const float* sums, const float* bsums,
                      const float* gamma, const float* beta, float eps, int silu,
@@ -139,6 +154,13 @@ typedef struct {
 } T2VAttn;
 int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream);
 int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream);
+
+/* ---- row softmax (VAE mid-block single-head attention, d=512: scores are materialised per frame through the
+ * batched GEMM).  In place allowed.  y[r,:] = softmax(x[r,:cols]) ---- */
+int t2v_softmax_rows(const void* x, long long ldx, void* y, long long ldy, long long rows, int cols, t2v_stream_t stream);
+/* y = keep(seed, row*cols+col) ? x/(1-p) : 0 — the mask the GEMM epilogue applies to a LoRA branch (utils/lora.py:49,119) */
+int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long long rows, int cols, float p,
+                     unsigned long long seed, t2v_stream_t stream);
 
 /* ---- elementwise ---- */
 /* GEGLU gate: y[m, j] = x[m, j] * gelu_erf(x[m, inner + j])  (FeedForward/GEGLU) */

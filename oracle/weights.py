@@ -21,13 +21,15 @@ def randomize_temporal_conv4(model, seed=7):
     return model
 
 
-def randomize_lora_up(model, seed=11):
+def randomize_lora_up(model, seed=11, scale=1.0):
+    """LoRA `up` factors ~ N(0, (scale/r)^2) (the reference initialises them to zero, utils/lora.py:55, which would
+    hide the whole LoRA branch from a parity test); scale=0 restores the reference init."""
     g = torch.Generator().manual_seed(seed)
     for m in model.modules():
         if hasattr(m, "lora_up") and hasattr(m, "lora_down"):
             with torch.no_grad():
                 w = m.lora_up.weight
-                w.copy_(torch.randn(w.shape, generator=g) / m.r)
+                w.copy_(torch.randn(w.shape, generator=g) * (scale / m.r))
     return model
 
 

@@ -104,7 +104,7 @@ def test_conv3d_temporal(B, Fr, C, HW):
 
 
 @pytest.mark.parametrize("nd,rows,C,G,silu", [(4, 63, 64, 32, True), (2, 1024, 320, 32, True), (1, 16 * 64, 640, 32, False),
-                                             (3, 10, 128, 32, False)])
+                                             (3, 10, 128, 32, False), (2, 48, 2560, 32, True)])
 def test_groupnorm(nd, rows, C, G, silu):
     import t2v_amd.functional as F
     g = torch.Generator().manual_seed(nd + rows + C)

@@ -163,6 +163,47 @@ __global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* __restrict_
   }
 }
 
+// row softmax: one wave per row, fp32 math, two passes over a bf16 row (row stays in L2/L1)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
+                                                            long long ldy, long long rows, int cols) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (long long r = (long long)blockIdx.x * 4 + wv; r < rows; r += (long long)gridDim.x * 4) {
+    const bf16_t* xr = x + r * ldx;
+    float mx = -INFINITY;
+    for (int c = lane * 8; c < cols; c += 512) {
+      bf16x8 v = *(const bf16x8*)(xr + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, bf2f((unsigned short)v[e]));
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane * 8; c < cols; c += 512) {
+      bf16x8 v = *(const bf16x8*)(xr + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += __expf(bf2f((unsigned short)v[e]) - mx);
+    }
+    const float inv = 1.f / wave_sum(sum);
+    for (int c = lane * 8; c < cols; c += 512) {
+      bf16x8 v = *(const bf16x8*)(xr + c), o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(__expf(bf2f((unsigned short)v[e]) - mx) * inv);
+      *(bf16x8*)(y + r * ldy + c) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
+                                                            long long ldy, long long rows, int cols, float p,
+                                                            unsigned long long seed) {
+  const float ks = 1.f / (1.f - p);
+  const long long n = rows * cols;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    long long r = i / cols;
+    int c = (int)(i - r * cols);
+    y[r * ldy + c] = drop_keep(seed, (unsigned long long)i, p) ? f2bf(bf2f(x[r * ldx + c]) * ks) : (bf16_t)0;
+  }
+}
+
 // direct convolution for tiny channel counts: one thread per (output position, output channel)
 __global__ __launch_bounds__(256) void smallconv_kernel(const T2VSmallConv p) {
   const T2VConvGeom g = p.geom;
@@ -256,6 +297,18 @@ __global__ void step_inc_kernel(int* step) { *step += 1; }
   T2V_CHECK_LAUNCH();                                                                       \
   return T2V_OK
 
+extern "C" int t2v_softmax_rows(const void* x, long long ldx, void* y, long long ldy, long long rows, int cols, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_softmax_rows: bad args");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((int)max(1LL, min((rows + 3) / 4, 16384LL))), dim3(256), 0, (hipStream_t)s,
+                     (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+extern "C" int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long long rows, int cols, float p,
+                                unsigned long long seed, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "t2v_dropout_mask: bad args");
+  LAUNCH1D(dropout_mask_kernel, rows * cols, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, p, seed);
+}
 extern "C" int t2v_geglu_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int inner, t2v_stream_t s) {
   T2V_CHECK_ARG(x && y && rows > 0 && inner > 0 && inner % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_geglu_fwd: bad args");
   LAUNCH1D(geglu_fwd_kernel, (long long)rows * (inner >> 3), s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (long long)rows, inner);

@@ -13,6 +13,8 @@
 // row-major operands (conflict-free ds_read_b128 fragments), padded K-major LDS image + ds_read_b64_tr_b16
 // hardware-transpose fragment reads for K-major operands, XCD-aware tile order (consecutive N tiles of one
 // M tile share an XCD/L2).
+#include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -49,6 +51,309 @@ __device__ __forceinline__ long long src_row(const Pos& p, int tap, const T2VCon
   int Hr = g.Hv >> g.up, Wr = g.Wv >> g.up;
   valid = v;
   return ((long long)p.n * Hr + (vy >> g.up)) * Wr + (vx >> g.up);
+}
+
+// one 8-column output chunk: alpha, dropout, bias, row-bias, activation, residual, store (or second output block)
+__device__ __forceinline__ void finish_chunk(const T2VGemm& p, float (&v)[8], long long row, int col, int z, long long zoffD,
+                                             long long zoffR) {
+  const int M = p.M, N = p.N;
+  const float* bias = (const float*)p.bias;
+  const bf16_t* rowbias = (const bf16_t*)p.rowbias;
+  const bf16_t* R = p.R ? (const bf16_t*)p.R + zoffR : nullptr;
+  const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  do {
+    const int nv = min(8, N - col);
+    const bool full = nv == 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    if (p.n_split > 0 && col >= p.n_split) {     // second output block (LoRA down projection): alpha only, bf16
+      bf16_t* dp = (bf16_t*)p.D2 + row * p.ldd2 + (col - p.n_split);
+      if (full) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[e]);
+        *(bf16x8*)dp = o;
+      } else {
+        for (int e = 0; e < nv; ++e) dp[e] = f2bf(v[e]);
+      }
+      break;
+    }
+    if (p.drop_p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        unsigned long long idx = ((unsigned long long)z * M + row) * N + col + e;
+        v[e] = drop_keep(p.drop_seed, idx, p.drop_p) ? v[e] * keep_scale : 0.f;
+      }
+    }
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nv) v[e] += bias[col + e];
+    }
+    if (rowbias) {
+      const bf16_t* rb = rowbias + (row / p.rows_per_rb) * p.ldrb + col;
+      if (full) {
+        bf16x8 t = *(const bf16x8*)rb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f((unsigned short)t[e]);
+      } else {
+        for (int e = 0; e < nv; ++e) v[e] += bf2f(rb[e]);
+      }
+    }
+    if (p.act == T2V_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    }
+    if (R) {
+      const bf16_t* rp = R + row * p.ldr + col;
+      if (full) {
+        bf16x8 t = *(const bf16x8*)rp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.beta * bf2f((unsigned short)t[e]);
+      } else {
+        for (int e = 0; e < nv; ++e) v[e] += p.beta * bf2f(rp[e]);
+      }
+    }
+    const long long di = zoffD + row * p.ldd + col;
+    if (p.out_mode == T2V_OUT_BF16) {
+      bf16_t* dp = (bf16_t*)p.D + di;
+      if (full) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[e]);
+        *(bf16x8*)dp = o;
+      } else {
+        for (int e = 0; e < nv; ++e) dp[e] = f2bf(v[e]);
+      }
+    } else if (p.out_mode == T2V_OUT_F32) {
+      float* dp = (float*)p.D + di;
+      if (full) {
+        *(float4*)dp = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(dp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        for (int e = 0; e < nv; ++e) dp[e] = v[e];
+      }
+    } else {
+      float* dp = (float*)p.D + di;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nv) atomicAdd(dp + e, v[e]);
+    }
+  } while (0);
+}
+
+// ---- shared epilogue: accumulators -> LDS (fp32) -> 16-byte coalesced rows (bias / rowbias / act / residual fused)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue(const T2VGemm& p, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], unsigned char* smem,
+                                         long long m0, int n0, int z, long long zoffD, long long zoffR) {
+  constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int M = p.M, N = p.N;
+  float* sC = (float*)smem;   // BM x BN fp32 fits in the (now idle) staging buffers
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int rl = wr * (FM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int cl = wc * (FN * 32) + j * 32 + (lane & 31);
+        sC[rl * BN + cl] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+#pragma unroll 1
+  for (int c = tid; c < BM * CPR; c += 256) {
+    const int rl = c / CPR, cc = c - rl * CPR;
+    const long long row = m0 + rl;
+    const int col = n0 + cc * 8;
+    if (row >= M || col >= N) continue;
+    float v[8];
+    {
+      const float4 a = *(const float4*)(sC + rl * BN + cc * 8);
+      const float4 b = *(const float4*)(sC + rl * BN + cc * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    if (p.ws_split > 1) {      // split-K partial: raw accumulate into the fp32 workspace, epilogue runs in the finalize pass
+      float* wp = (float*)p.workspace + row * (long long)N + col;
+      const int nvv = min(8, N - col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nvv) atomicAdd(wp + e, v[e]);
+      continue;
+    }
+    finish_chunk(p, v, row, col, z, zoffD, zoffR);
+  }
+}
+
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[64];   // source for predicated-off LDS-DMA lanes (zero padding)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// NN kernel, LDS-DMA pipeline: operands stream HBM/L2 -> LDS with global_load_lds (16 B per lane, no VGPR staging)
+// through an NSTAGE-deep ring; counted s_waitcnt vmcnt(N) + one raw s_barrier per K step keep NSTAGE-2 tiles in
+// flight across the barrier, so small, latency-bound shapes (most of this UNet at batch 1) no longer serialise on a
+// single prefetch.  LDS image is lane-linear (what the DMA writes); the XOR swizzle is applied to the per-lane
+// SOURCE chunk and to the fragment reads (same involution).  Conv zero padding / edge rows read a zero page.
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_kernel_dma(const T2VGemm p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int NCA = BM / 32, NCB = BN / 32, LPT = NCA + NCB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int M = p.M, N = p.N;
+  const T2VConvGeom g = p.geom;
+  const int ntn = (N + BN - 1) / BN;
+  const int ntiles = gridDim.x;
+  int t;
+  {
+    int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = t / ntn, tn = t - tm * ntn;
+  const long long m0 = (long long)tm * BM;
+  const int n0 = tn * BN;
+  const int z = blockIdx.z;
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+  long long zoffD = 0, zoffR = 0;
+  int kbeg = 0, kend = p.K;
+  if (p.ws_split > 1) {
+    int per = ((p.K + p.ws_split - 1) / p.ws_split + BK - 1) / BK * BK;
+    kbeg = z * per;
+    kend = min(p.K, kbeg + per);
+    if (kbeg >= kend) return;
+  } else {
+    A += (long long)z * p.strideA;
+    B += (long long)z * p.strideB;
+    zoffD = (long long)z * p.strideD;
+    zoffR = (long long)z * p.strideR;
+  }
+  const bf16_t* zp = (const bf16_t*)g_zero_page;
+
+  // chunk c = tid + 256*i of a tile sits at LDS byte c*16 (row c>>3, slot c&7) and holds source chunk slot^swz(row)
+  const int kc = (tid & 7) ^ ((tid >> 4) & 7);          // (row>>1)&7 is the same for all i: rows differ by 32*i
+  Pos posA[NCA];
+  const bf16_t* arow[NCA];
+  bool aok[NCA];
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) {
+    long long m = m0 + (tid >> 3) + 32 * i;
+    aok[i] = m < M;
+    if (p.a_mode == T2V_A_CONV) {
+      posA[i] = decompose(m, M, g);
+      arow[i] = A;
+    } else {
+      posA[i] = Pos{0, 0, 0, 0};
+      arow[i] = A + (aok[i] ? m : 0) * p.lda;
+    }
+  }
+  const bf16_t* brow[NCB];
+  bool bok[NCB];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    int n = n0 + (tid >> 3) + 32 * i;
+    bok[i] = n < N;
+    if (p.n_split > 0 && n >= p.n_split)
+      brow[i] = (const bf16_t*)p.B2 + (long long)(bok[i] ? n - p.n_split : 0) * p.ldb2;
+    else
+      brow[i] = B + (long long)(bok[i] ? n : 0) * p.ldb;
+  }
+
+  auto issue = [&](int k0, int stage) {
+    unsigned char* sA = smem + stage * STAGE;
+    unsigned char* sB = sA + A_BYTES;
+    const int kidx = k0 + kc * 8;
+    const bool kok = kidx < kend;
+    if (p.a_mode == T2V_A_CONV) {
+      const int tap = kidx / g.C;
+      const int c = kidx - tap * g.C;
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) {
+        bool v;
+        long long sr = src_row(posA[i], tap, g, v);
+        const bf16_t* src = (v && kok) ? A + sr * p.lda + c : zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sA + (tid + 256 * i) * 16), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) {
+        const bf16_t* src = (aok[i] && kok) ? arow[i] + kidx : zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sA + (tid + 256 * i) * 16), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const bf16_t* src = (bok[i] && kok) ? brow[i] + kidx : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sB + (tid + 256 * i) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int stage) {
+    const unsigned char* sA = smem + stage * STAGE;
+    const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        int row = wr * (FM * 32) + i * 32 + (lane & 31);
+        int kch = kk * 2 + (lane >> 5);
+        af[i] = *(const bf16x8*)(sA + row * 128 + ((kch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int row = wc * (FN * 32) + j * 32 + (lane & 31);
+        int kch = kk * 2 + (lane >> 5);
+        bfr[j] = *(const bf16x8*)(sB + row * 128 + ((kch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nt = (kend - kbeg + BK - 1) / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nt) issue(kbeg + s * BK, s);
+  int stage = 0;
+  for (int it = 0; it < nt; ++it) {
+    const int ahead = min(nt, it + NSTAGE - 1) - (it + 1);      // tiles allowed to stay in flight
+    if (ahead >= 2) wait_vmcnt<2 * LPT>();
+    else if (ahead == 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                                // tile `it` landed for every wave; stage (it-1)%S is free
+    if (it + NSTAGE - 1 < nt) {
+      int ws = stage + NSTAGE - 1;
+      if (ws >= NSTAGE) ws -= NSTAGE;
+      issue(kbeg + (it + NSTAGE - 1) * BK, ws);
+    }
+    compute(stage);
+    if (++stage == NSTAGE) stage = 0;
+  }
+  wait_vmcnt<0>();
+  __syncthreads();                                               // ring is idle: reuse it for the epilogue staging
+  epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, z, zoffD, zoffR);
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
@@ -123,7 +428,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
     for (int i = 0; i < NCB; ++i) {
       int n = n0 + (tid >> 3) + 32 * i;
       bok[i] = n < N;
-      brow[i] = B + (long long)(bok[i] ? n : 0) * p.ldb;
+      if (p.n_split > 0 && n >= p.n_split)
+        brow[i] = (const bf16_t*)p.B2 + (long long)(bok[i] ? n - p.n_split : 0) * p.ldb2;
+      else
+        brow[i] = B + (long long)(bok[i] ? n : 0) * p.ldb;
     }
   } else if (p.b_conv) {
     int nn = n0 + (tid % (BN / 8)) * 8;
@@ -180,6 +488,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
           long long sr = src_row(ps, btap, g, v2);
           v = v && v2;
           rb[i] = v ? *(const bf16x8*)(B + sr * p.ldb + bc) : zero8;
+        } else if (p.b_tapflip) {
+          int tapi = kk / g.C, jr = kk - tapi * g.C;
+          rb[i] = v ? *(const bf16x8*)(B + (long long)jr * p.ldb + (long long)(g.KH * g.KW - 1 - tapi) * N + nn) : zero8;
         } else {
           rb[i] = v ? *(const bf16x8*)(B + (long long)kk * p.ldb + nn) : zero8;
         }
@@ -284,41 +595,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
     __syncthreads();
   }
 
-  // ---- epilogue
-  const float* bias = (const float*)p.bias;
-  const bf16_t* rowbias = (const bf16_t*)p.rowbias;
-  const bf16_t* R = p.R ? (const bf16_t*)p.R + zoffR : nullptr;
-  const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int col = n0 + wc * (FN * 32) + j * 32 + (lane & 31);
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long row = m0 + wr * (FM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
-        float v = p.alpha * acc[i][j][r];
-        if (p.drop_p > 0.f) {
-          unsigned long long idx = ((unsigned long long)z * M + row) * N + col;
-          v = drop_keep(p.drop_seed, idx, p.drop_p) ? v * keep_scale : 0.f;
-        }
-        v += bv;
-        if (rowbias) v += bf2f(rowbias[(row / p.rows_per_rb) * p.ldrb + col]);
-        if (p.act == T2V_ACT_SILU) v = silu_f(v);
-        if (R) v += p.beta * bf2f(R[row * p.ldr + col]);
-        const long long di = zoffD + row * p.ldd + col;
-        if (p.out_mode == T2V_OUT_BF16)
-          ((bf16_t*)p.D)[di] = f2bf(v);
-        else if (p.out_mode == T2V_OUT_F32)
-          ((float*)p.D)[di] = v;
-        else
-          atomicAdd((float*)p.D + di, v);
-      }
-    }
-  }
+  epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, z, zoffD, zoffR);
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
@@ -339,6 +616,41 @@ int launch(const T2VGemm& p, hipStream_t s) {
   return T2V_OK;
 }
 
+bool g_force_regstage = false;   // T2V_GEMM_REGSTAGE=1: A/B the register-staged mainloop against the LDS-DMA pipeline
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_dma(const T2VGemm& p, hipStream_t s) {
+  constexpr int RING = NSTAGE * (BM + BN) * BK * 2;
+  constexpr int SMEM = RING > BM * BN * 4 ? RING : BM * BN * 4;
+  auto kern = gemm_kernel_dma<BM, BN, WM, WN, NSTAGE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (SMEM > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, 1, p.ws_split > 1 ? p.ws_split : (p.batch > 1 ? p.batch : 1));
+  hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+// finalize pass of a workspace split-K launch: full epilogue over the fp32 partial sums
+__global__ __launch_bounds__(256) void gemm_finalize_kernel(const T2VGemm p) {
+  const int cpr = (p.N + 7) / 8;
+  const long long n = (long long)p.M * cpr;
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < n; c += (long long)gridDim.x * 256) {
+    const long long row = c / cpr;
+    const int col = (int)(c - row * cpr) * 8;
+    const float* wp = (const float*)p.workspace + row * (long long)p.N + col;
+    float v[8];
+    const int nv = min(8, p.N - col);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e < nv ? wp[e] : 0.f;
+    finish_chunk(p, v, row, col, 0, 0, 0);
+  }
+}
+
 // pick the tile that minimises (waves of workgroups) x (tile cost); ~2 workgroups resident per CU
 template <bool AT, bool BT>
 int dispatch(const T2VGemm& p, hipStream_t s) {
@@ -348,9 +660,47 @@ int dispatch(const T2VGemm& p, hipStream_t s) {
     long long waves = (tiles + 511) / 512;
     return (double)waves * bm * bn / eff;
   };
+  constexpr bool DMA = !AT && !BT;
+  const bool dma = DMA && p.split_k <= 1 && !g_force_regstage;
+  if constexpr (DMA) {
+    // deep-K, few-tile launches (the 4x4/8x8-resolution layers at batch 1, LoRA dt = dy U): split K across workgroups
+    // through the caller's fp32 workspace, then run the epilogue in a finalize pass
+    if (dma && p.ws_split == 0 && p.workspace && p.batch <= 1 && p.out_mode == T2V_OUT_BF16) {
+      int bm = 64, bn = 64;
+      if (p.N <= 32) { bm = 128; bn = 32; }
+      long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+      int split = (int)std::min<long long>(std::min<long long>(384 / std::max<long long>(1, tiles), p.K / 256), 32);
+      if (tiles <= 96 && split >= 2 && (size_t)p.M * p.N * 4 <= p.workspace_bytes) {
+        T2VGemm q = p;
+        q.ws_split = split;
+        if (hipMemsetAsync(p.workspace, 0, (size_t)p.M * p.N * 4, s) != hipSuccess) {
+          t2v_set_error("t2v_gemm: workspace memset failed");
+          return T2V_ELAUNCH;
+        }
+        int rc = (p.N <= 32) ? launch_dma<128, 32, 4, 1, 4>(q, s) : launch_dma<64, 64, 2, 2, 4>(q, s);
+        if (rc) return rc;
+        q.ws_split = 1;
+        long long nchunk = (long long)p.M * ((p.N + 7) / 8);
+        hipLaunchKernelGGL(gemm_finalize_kernel, dim3((int)std::min<long long>((nchunk + 255) / 256, 4096)), dim3(256), 0, s, q);
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+      }
+    }
+  }
+  if (p.N <= 32) {   // skinny outputs (LoRA rank): HBM-bound on A
+    if constexpr (DMA) { if (dma) return launch_dma<128, 32, 4, 1, 4>(p, s); }
+    return launch<128, 32, 4, 1, AT, BT>(p, s);
+  }
   double c0 = cost(128, 128, 1.0), c1 = cost(128, 64, 0.8), c2 = cost(64, 64, 0.55);
-  if (c0 <= c1 && c0 <= c2) return launch<128, 128, 2, 2, AT, BT>(p, s);
-  if (c1 <= c2) return launch<128, 64, 2, 2, AT, BT>(p, s);
+  if (c0 <= c1 && c0 <= c2) {
+    if constexpr (DMA) { if (dma) return launch_dma<128, 128, 2, 2, 3>(p, s); }
+    return launch<128, 128, 2, 2, AT, BT>(p, s);
+  }
+  if (c1 <= c2) {
+    if constexpr (DMA) { if (dma) return launch_dma<128, 64, 2, 2, 4>(p, s); }
+    return launch<128, 64, 2, 2, AT, BT>(p, s);
+  }
+  if constexpr (DMA) { if (dma) return launch_dma<64, 64, 2, 2, 4>(p, s); }
   return launch<64, 64, 2, 2, AT, BT>(p, s);
 }
 
@@ -364,6 +714,10 @@ extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
   T2V_CHECK_ARG((p.a_trans && p.b_trans) || p.K % 8 == 0, "t2v_gemm: K=%d must be a multiple of 8", p.K);
   T2V_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0, "t2v_gemm: lda=%lld ldb=%lld must be multiples of 8", p.lda, p.ldb);
   T2V_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "t2v_gemm: operands must be 16-byte aligned");
+  T2V_CHECK_ARG(p.ldd % 8 == 0 && ((uintptr_t)p.D & 15) == 0, "t2v_gemm: D must be 16-byte aligned with ldd%%8==0 (ldd=%lld)", p.ldd);
+  T2V_CHECK_ARG(!p.R || (p.ldr % 8 == 0 && ((uintptr_t)p.R & 15) == 0), "t2v_gemm: R must be 16-byte aligned with ldr%%8==0");
+  T2V_CHECK_ARG(!p.rowbias || (p.ldrb % 8 == 0 && ((uintptr_t)p.rowbias & 15) == 0), "t2v_gemm: rowbias must be 16-byte aligned, ldrb%%8==0");
+  T2V_CHECK_ARG(p.batch <= 1 || (p.strideD % 8 == 0 && p.strideR % 8 == 0), "t2v_gemm: batch strides must be multiples of 8");
   T2V_CHECK_ARG(!(p.split_k > 1 && p.batch > 1), "t2v_gemm: split_k and batch are exclusive");
   T2V_CHECK_ARG(!(p.split_k > 1) || p.out_mode == T2V_OUT_F32_ATOMIC, "t2v_gemm: split_k needs atomic fp32 output");
   if (p.a_mode == T2V_A_CONV || p.b_conv) {
@@ -384,7 +738,21 @@ extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
   if (p.a_trans) T2V_CHECK_ARG(p.M % 8 == 0, "t2v_gemm: a_trans needs M%%8==0 (M=%d)", p.M);
   if (p.b_trans) T2V_CHECK_ARG(p.N % 8 == 0, "t2v_gemm: b_trans needs N%%8==0 (N=%d)", p.N);
   if (p.rowbias) T2V_CHECK_ARG(p.rows_per_rb > 0, "t2v_gemm: rows_per_rb must be > 0");
+  if (p.n_split > 0) {
+    T2V_CHECK_ARG(!p.b_trans && p.B2 && p.D2 && p.n_split % 8 == 0 && p.n_split < p.N && p.ldb2 % 8 == 0 && p.ldd2 % 8 == 0 &&
+                      p.out_mode == T2V_OUT_BF16 && p.batch <= 1 && p.split_k <= 1,
+                  "t2v_gemm: bad split-output arguments (n_split=%d)", p.n_split);
+  }
+  if (p.b_tapflip)
+    T2V_CHECK_ARG(p.b_trans && !p.b_conv && p.a_mode == T2V_A_CONV && p.K == p.geom.KH * p.geom.KW * p.geom.C,
+                  "t2v_gemm: b_tapflip needs b_trans=1 and a conv gather on A");
   hipStream_t s = (hipStream_t)stream;
+  static const bool env_init = [] {
+    const char* e = getenv("T2V_GEMM_REGSTAGE");
+    g_force_regstage = e && e[0] == '1';
+    return true;
+  }();
+  (void)env_init;
   if (!p.a_trans && !p.b_trans) return dispatch<false, false>(p, s);
   if (p.a_trans && p.b_trans) return dispatch<true, true>(p, s);
   if (!p.a_trans && p.b_trans) return dispatch<false, true>(p, s);

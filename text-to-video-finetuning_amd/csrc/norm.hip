@@ -7,118 +7,126 @@
 namespace {
 
 // ------------------------------------------------------------------ GroupNorm statistics
-// grid (nsplit, ndomains); each block reduces a slab of rows of one domain over all channels.
+// grid (nsplit, ndomains); each block reduces a slab of rows of one domain over all channels and writes its
+// per-group partial (no atomics: fixed-order LDS reduction + a finalize pass => bit-reproducible statistics).
+constexpr int GN_MAX_SPLIT = 64;
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, long long ldx,
                                                         const bf16_t* __restrict__ dy, long long lddy,
                                                         int rows_per_domain, int C, int G, const float* __restrict__ sums,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int silu, float drop_p, unsigned long long drop_seed,
-                                                        float* __restrict__ out, float* __restrict__ dgamma,
+                                                        float* __restrict__ partial, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta) {
-  extern __shared__ float sbin[];  // [G][2]
+  __shared__ float sval[256 * 17];   // per-thread (8 sums, 8 second sums), row stride 17 to dodge bank conflicts
   const int d = blockIdx.y, tid = threadIdx.x;
-  const int tpr = C >> 3, rpp = 256 / tpr;
-  const int cc = tid % tpr, rl = tid / tpr;
+  const int nchunks = C >> 3;
+  const int tpr = min(nchunks, 256), rpp = 256 / tpr;
+  const int ncb = (nchunks + tpr - 1) / tpr;          // column blocks (C > 2048 -> more than one)
+  const int rl = tid / tpr;
   const int cpg = C / G;
-  for (int i = tid; i < 2 * G; i += 256) sbin[i] = 0.f;
-  __syncthreads();
   const int rows_per_split = (rows_per_domain + gridDim.x - 1) / gridDim.x;
   const int rbeg = blockIdx.x * rows_per_split, rend = min(rows_per_domain, rbeg + rows_per_split);
-  float s0[8], s1[8];
+  float gacc = 0.f;                                   // thread t < 2G owns (group t>>1, moment t&1)
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int cc = cb * tpr + tid % tpr;
+    const bool active = (rl < rpp) && (cc < nchunks);
+    float s0[8], s1[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
-  float mean[8], rstd[8], gm[8], bt[8];
-  if (BWD) {
-    const float cnt = (float)rows_per_domain * cpg;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = cc * 8 + e;
-      if (rl < rpp) {
-        int gi = c / cpg;
-        float mu = sums[(d * G + gi) * 2] / cnt;
-        float var = fmaxf(sums[(d * G + gi) * 2 + 1] / cnt - mu * mu, 0.f);
-        mean[e] = mu;
-        rstd[e] = rsqrtf(var + eps);
-        gm[e] = gamma[c];
-        bt[e] = beta[c];
-      }
-    }
-  }
-  if (rl < rpp) {
-    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (int r = rbeg + rl; r < rend; r += rpp) {
-      const long long row = (long long)d * rows_per_domain + r;
-      bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
-      if (!BWD) {
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    if (active) {
+      float mean[8], rstd[8], gm[8], bt[8];
+      if (BWD) {
+        const float cnt = (float)rows_per_domain * cpg;
+        int gi = (cc * 8) / cpg, rem = (cc * 8) - gi * cpg;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float v = bf2f((unsigned short)xv[e]);
-          s0[e] += v;
-          s1[e] += v * v;
-        }
-      } else {
-        bf16x8 gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
-          float dz = bf2f((unsigned short)gv[e]);
-          if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
-          if (silu) {
-            float zz = xh * gm[e] + bt[e];
-            float sg = sigmoid_f(zz);
-            dz *= sg * (1.f + zz * (1.f - sg));
-          }
-          s0[e] += dz * gm[e];           // sum dxh
-          s1[e] += dz * gm[e] * xh;      // sum dxh * xh
-          if (dgamma) {                  // reuse mean/rstd regs? keep separate accumulators in LDS-free form
-            // per-channel parameter grads are accumulated below through atomics on (dz*xh, dz)
+          const int c = cc * 8 + e;
+          float mu = sums[(d * G + gi) * 2] / cnt;
+          float var = fmaxf(sums[(d * G + gi) * 2 + 1] / cnt - mu * mu, 0.f);
+          mean[e] = mu;
+          rstd[e] = rsqrtf(var + eps);
+          gm[e] = gamma[c];
+          bt[e] = beta[c];
+          if (++rem == cpg) {
+            rem = 0;
+            ++gi;
           }
         }
       }
-    }
-    // per-channel parameter gradients (full finetune only): second light pass keeps register pressure low
-    if (BWD && dgamma) {
+      const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
       float a0[8], a1[8];
+      if (BWD && dgamma) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+        for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+      }
       for (int r = rbeg + rl; r < rend; r += rpp) {
         const long long row = (long long)d * rows_per_domain + r;
         bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
-        bf16x8 gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
+        if (!BWD) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
-          float dz = bf2f((unsigned short)gv[e]);
-          if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
-          if (silu) {
-            float zz = xh * gm[e] + bt[e];
-            float sg = sigmoid_f(zz);
-            dz *= sg * (1.f + zz * (1.f - sg));
+          for (int e = 0; e < 8; ++e) {
+            float v = bf2f((unsigned short)xv[e]);
+            s0[e] += v;
+            s1[e] += v * v;
           }
-          a0[e] += dz * xh;
-          a1[e] += dz;
+        } else {
+          bf16x8 gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
+            float dz = bf2f((unsigned short)gv[e]);
+            if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
+            if (silu) {
+              float zz = xh * gm[e] + bt[e];
+              float sg = sigmoid_f(zz);
+              dz *= sg * (1.f + zz * (1.f - sg));
+            }
+            s0[e] += dz * gm[e];           // sum dxh
+            s1[e] += dz * gm[e] * xh;      // sum dxh * xh
+            if (dgamma) {
+              a0[e] += dz * xh;
+              a1[e] += dz;
+            }
+          }
         }
       }
+      if (BWD && dgamma) {                 // per-channel parameter gradients (full finetune only)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(dgamma + cc * 8 + e, a0[e]);
-        atomicAdd(dbeta + cc * 8 + e, a1[e]);
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(dgamma + cc * 8 + e, a0[e]);
+          atomicAdd(dbeta + cc * 8 + e, a1[e]);
+        }
       }
     }
-    int gi = (cc * 8) / cpg, rem = (cc * 8) - gi * cpg;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      atomicAdd(&sbin[gi * 2], s0[e]);
-      atomicAdd(&sbin[gi * 2 + 1], s1[e]);
-      if (++rem == cpg) {
-        rem = 0;
-        ++gi;
+      sval[tid * 17 + e] = s0[e];
+      sval[tid * 17 + 8 + e] = s1[e];
+    }
+    __syncthreads();
+    if (tid < 2 * G) {
+      const int g = tid >> 1, which = tid & 1;
+      const int clo = max(g * cpg, cb * tpr * 8), chi = min((g + 1) * cpg, min(C, (cb + 1) * tpr * 8));
+      for (int c = clo; c < chi; ++c) {
+        const int chl = (c >> 3) - cb * tpr, e = c & 7;
+        for (int q = 0; q < rpp; ++q) gacc += sval[(q * tpr + chl) * 17 + which * 8 + e];
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = tid; i < 2 * G; i += 256) atomicAdd(out + (long long)d * G * 2 + i, sbin[i]);
+  if (tid < 2 * G) partial[(((long long)d * gridDim.x + blockIdx.x) * G) * 2 + tid] = gacc;
+}
+
+// sums[d][g][w] = sum over splits (fixed order)
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nsplit, int G2) {
+  const int d = blockIdx.x;
+  for (int t = threadIdx.x; t < G2; t += blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) a += partial[((long long)d * nsplit + s) * G2 + t];
+    sums[(long long)d * G2 + t] = a;
+  }
 }
 
 // ------------------------------------------------------------------ GroupNorm apply (fwd) / dx (bwd)
@@ -310,28 +318,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 }
 
 int gn_check(const char* fn, int C, int G, long long ldx) {
-  if (C <= 0 || G <= 0 || C % G != 0 || C % 8 != 0 || C > 2048 || ldx % 8 != 0) {
-    t2v_set_error("%s: need C%%G==0, C%%8==0, C<=2048, ld%%8==0 (C=%d G=%d ld=%lld)", fn, C, G, ldx);
+  if (C <= 0 || G <= 0 || C % G != 0 || C % 8 != 0 || ldx % 8 != 0) {
+    t2v_set_error("%s: need C%%G==0, C%%8==0, ld%%8==0 (C=%d G=%d ld=%lld)", fn, C, G, ldx);
     return T2V_EINVAL;
   }
   return T2V_OK;
 }
 int gn_splits(int ndomains, int rows_per_domain, int C) {
-  int rpp = 256 / (C >> 3);
+  int rpp = 256 / min(C >> 3, 256);
   int want = max(1, 2048 / max(1, ndomains));
   int maxs = max(1, rows_per_domain / (rpp * 4));
-  return max(1, min(want, maxs));
+  return max(1, min(GN_MAX_SPLIT, min(want, maxs)));
 }
 }  // namespace
 
+extern "C" long long t2v_gn_workspace_floats(int ndomains, int G) { return (long long)ndomains * GN_MAX_SPLIT * G * 2; }
+
 extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows_per_domain, int C, int G, float* sums,
-                            t2v_stream_t stream) {
+                            float* workspace, t2v_stream_t stream) {
   if (int e = gn_check("t2v_gn_stats", C, G, ldx)) return e;
-  T2V_CHECK_ARG(x && sums && ndomains > 0 && rows_per_domain > 0, "t2v_gn_stats: bad args");
-  dim3 grid(gn_splits(ndomains, rows_per_domain, C), ndomains);
-  hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 2 * G * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, nullptr, 0, rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull,
-                     sums, nullptr, nullptr);
+  T2V_CHECK_ARG(x && sums && workspace && ndomains > 0 && rows_per_domain > 0 && G <= 128, "t2v_gn_stats: bad args");
+  const int ns = gn_splits(ndomains, rows_per_domain, C);
+  dim3 grid(ns, ndomains);
+  hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0,
+                     rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, workspace, nullptr, nullptr);
+  T2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ndomains), dim3(64), 0, (hipStream_t)stream, workspace, sums, ns, 2 * G);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -353,15 +365,17 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
 
 extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long lddy, int ndomains,
                                 int rows_per_domain, int C, int G, const float* sums, const float* gamma, const float* beta,
-                                float eps, int silu, float drop_p, unsigned long long drop_seed, float* bsums, float* dgamma,
-                                float* dbeta, t2v_stream_t stream) {
+                                float eps, int silu, float drop_p, unsigned long long drop_seed, float* bsums, float* workspace,
+                                float* dgamma, float* dbeta, t2v_stream_t stream) {
   if (int e = gn_check("t2v_gn_bwd_stats", C, G, ldx)) return e;
-  T2V_CHECK_ARG(x && dy && sums && gamma && beta && bsums && lddy % 8 == 0, "t2v_gn_bwd_stats: bad args");
+  T2V_CHECK_ARG(x && dy && sums && gamma && beta && bsums && workspace && lddy % 8 == 0 && G <= 128, "t2v_gn_bwd_stats: bad args");
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_gn_bwd_stats: dgamma/dbeta must both be set or NULL");
-  dim3 grid(gn_splits(ndomains, rows_per_domain, C), ndomains);
-  hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 2 * G * sizeof(float), (hipStream_t)stream, (const bf16_t*)x,
-                     ldx, (const bf16_t*)dy, lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed,
-                     bsums, dgamma, dbeta);
+  const int ns = gn_splits(ndomains, rows_per_domain, C);
+  dim3 grid(ns, ndomains);
+  hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, workspace, dgamma, dbeta);
+  T2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ndomains), dim3(64), 0, (hipStream_t)stream, workspace, bsums, ns, 2 * G);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

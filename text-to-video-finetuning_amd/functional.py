@@ -82,11 +82,11 @@ LINEAR = ConvCfg()
 
 
 # --------------------------------------------------------------------------- weight preparation (bf16 GEMM layouts)
-_wcache = {}
-
-
-def clear_weight_cache():
-    _wcache.clear()
+def clear_weight_cache(model=None):
+    """Drop cached prepared copies (they live on the Parameter objects themselves, so they die with the model)."""
+    if model is not None:
+        for p in model.parameters():
+            p.__dict__.pop("_t2v_prep", None)
 
 
 def _prep_compute(w, kind, cfg):
@@ -116,16 +116,18 @@ def _prep_compute(w, kind, cfg):
 
 
 def prepared_weight(w, kind):
-    """bf16 GEMM-layout copy of a parameter.  Frozen parameters are cached (keyed on storage + version);
-    trainable ones are re-derived every call so optimizer updates (and graph replays) always see fresh values."""
-    if w.requires_grad:
+    """bf16 GEMM-layout copy of a parameter.  Frozen parameters cache it ON THE PARAMETER OBJECT (validated against
+    storage address + version, so a re-homed / updated / re-allocated tensor can never hit a stale copy); trainable
+    ones are re-derived every call so optimizer updates (and graph replays) always see fresh values."""
+    if w.requires_grad or not isinstance(w, torch.nn.Parameter):
         return _prep_compute(w, kind, None)
-    key = (w.data_ptr(), tuple(w.shape), w.dtype, w._version, kind)
-    hit = _wcache.get(key)
-    if hit is None:
-        hit = _prep_compute(w, kind, None)
-        _wcache[key] = hit
-    return hit
+    cache = w.__dict__.setdefault("_t2v_prep", {})
+    hit = cache.get(kind)
+    tag = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+    if hit is None or hit[0] != tag:
+        hit = (tag, _prep_compute(w, kind, None))
+        cache[kind] = hit
+    return hit[1]
 
 
 def _f32(t):
@@ -145,7 +147,8 @@ def _pad_vec(v, n):
 # --------------------------------------------------------------------------- raw launches
 def launch_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0, b_conv=0, geom=None, out_mode=0,
                 bias=None, rowbias=None, ldrb=0, rows_per_rb=0, R=None, ldr=0, alpha=1.0, beta=1.0, act=0, batch=1,
-                strideA=0, strideB=0, strideD=0, strideR=0, split_k=1, drop_p=0.0, drop_seed=0):
+                strideA=0, strideB=0, strideD=0, strideR=0, split_k=1, drop_p=0.0, drop_seed=0, B2=None, ldb2=0, n_split=0,
+                D2=None, ldd2=0, b_tapflip=0):
     g = Gemm = nv.Gemm()
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.a_mode, g.a_trans = A, lda, a_mode, a_trans
@@ -160,7 +163,23 @@ def launch_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans
     g.batch, g.strideA, g.strideB, g.strideD, g.strideR = batch, strideA, strideB, strideD, strideR
     g.split_k = split_k
     g.drop_p, g.drop_seed = drop_p, drop_seed
+    g.B2, g.ldb2, g.n_split, g.D2, g.ldd2, g.b_tapflip = B2, ldb2, n_split, D2, ldd2, b_tapflip
+    if out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
+        ws = _gemm_workspace()
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     nv.call("t2v_gemm", C.byref(g), nv.stream())
+
+
+_gemm_ws = {}
+
+
+def _gemm_workspace():
+    """fp32 scratch for library-side split-K (one per device; stream order serialises its users)."""
+    dev = torch.cuda.current_device()
+    buf = _gemm_ws.get(dev)
+    if buf is None:
+        buf = _gemm_ws[dev] = torch.empty(8 << 20, dtype=torch.float32, device=f"cuda:{dev}")   # 32 MB
+    return buf
 
 
 def _split_k(tiles, kdim):
@@ -225,7 +244,6 @@ class _ConvLinear(torch.autograd.Function):
         if drop_p > 0.0:
             # dropout sits between the GEMM and bias/residual: re-apply the same mask to dy
             g = torch.empty_like(dy)
-            ones = None
             launch_gemm_dropmask(dy, g, drop_p, drop_seed)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -262,7 +280,9 @@ class _ConvLinear(torch.autograd.Function):
 
 
 def launch_gemm_dropmask(dy, out, drop_p, drop_seed):
-    raise RuntimeError("t2v_amd: LoRA-branch dropout backward is not wired yet (run with eval_train / dropout off)")
+    """Re-apply the GEMM epilogue's dropout mask (index = row * N + col) to the incoming gradient."""
+    nv.call("t2v_dropout_mask", dy.data_ptr(), _ld(dy), out.data_ptr(), _ld(out), dy.shape[0], dy.shape[1], drop_p,
+            drop_seed, nv.stream())
 
 
 def _unprep_weight_grad(dwp, weight, cfg):
@@ -280,11 +300,117 @@ def _unprep_weight_grad(dwp, weight, cfg):
     return gw.to(weight.dtype).contiguous()
 
 
+class _LoraLayer(torch.autograd.Function):
+    """One LoRA-wrapped layer: y = base(x) + scale * up(down(x)) (utils/lora.py:57-62,134-139,211-216, dropout off /
+    identity selector) with the factors living in the trainer's flat buffers (lora_bank.py):
+      fwd : [y | t] = x (*) [W ; D]^T in ONE launch (the down projection rides as extra output columns), y += s t U^T
+      bwd : dt = s dy U ; dx = dy (*) W^T + dt (*) D^T ; dU += s dy^T t ; dD += dt^T x   (TN GEMMs accumulate straight
+            into the flat fp32 gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, e, scale):
+        x = _mat(x, "x")
+        wq = prepared_weight(w_base, "fwd")
+        npad, K = wq.shape
+        cin_p = K // cfg.taps()
+        if x.shape[1] != cin_p or npad != e.npad or cin_p != e.cin_p:
+            raise RuntimeError("t2v_amd: LoRA bank entry does not match the layer")
+        M = x.shape[0] if cfg.kind == "linear" else cfg.nimg * cfg.Ho * cfg.Wo
+        y = torch.empty(M, npad, dtype=BF16, device=x.device)
+        t = torch.empty(M, e.rp, dtype=BF16, device=x.device)
+        b32 = _pad_vec(_f32(b_base), npad)
+        rpr = 0
+        if rowbias is not None:
+            rowbias = _mat(rowbias, "rowbias")
+            rpr = M // rowbias.shape[0]
+        if residual is not None:
+            residual = _mat(residual, "residual")
+        conv = cfg.kind != "linear"
+        launch_gemm(M=M, N=npad + e.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=npad,
+                    a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(cin_p) if conv else None, bias=nv.ptr(b32),
+                    rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
+                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
+                    B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
+        launch_gemm(M=M, N=npad, K=e.rp, A=t.data_ptr(), lda=e.rp, B=e.up_w16.data_ptr(), ldb=e.rp, D=y.data_ptr(), ldd=npad,
+                    R=y.data_ptr(), ldr=npad, alpha=scale)
+        ctx.cfg, ctx.e, ctx.scale = cfg, e, scale
+        ctx.has = (rowbias is not None, residual is not None)
+        ctx.save_for_backward(x, t, w_base, rowbias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, t, w_base, rowbias = ctx.saved_tensors
+        cfg, e, scale = ctx.cfg, ctx.e, ctx.scale
+        has_rb, has_res = ctx.has
+        dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        M, npad = dy.shape
+        conv = cfg.kind != "linear"
+        dres = dy if has_res else None
+        drb = None
+        if has_rb:
+            drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
+        dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)
+        launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=e.rp, b_trans=1,
+                    D=dt.data_ptr(), ldd=e.rp, alpha=scale)
+        dx = None
+        cin_p = e.cin_p
+        if ctx.needs_input_grad[0]:
+            wb = prepared_weight(w_base, "bwd")
+            if not conv:
+                dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+                launch_gemm(M=M, N=cin_p, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
+                            D=dx.data_ptr(), ldd=cin_p)
+                launch_gemm(M=M, N=cin_p, K=e.rp, A=dt.data_ptr(), lda=e.rp, B=e.down_w16.data_ptr(), ldb=cin_p, b_trans=1,
+                            D=dx.data_ptr(), ldd=cin_p, R=dx.data_ptr(), ldr=cin_p)
+            else:
+                Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
+                Mi = cfg.nimg * Hv * Wv
+                dxv = torch.empty(Mi, cin_p, dtype=BF16, device=dy.device)
+                launch_gemm(M=Mi, N=cin_p, K=wb.shape[1], A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
+                            D=dxv.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(npad))
+                launch_gemm(M=Mi, N=cin_p, K=cfg.taps() * e.rp, A=dt.data_ptr(), lda=e.rp, B=e.down_w16.data_ptr(),
+                            ldb=cfg.taps() * cin_p, b_trans=1, b_tapflip=1, D=dxv.data_ptr(), ldd=cin_p, R=dxv.data_ptr(),
+                            ldr=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(e.rp))
+                if cfg.up:
+                    dx = torch.empty(cfg.nimg * cfg.H * cfg.W, cin_p, dtype=BF16, device=dy.device)
+                    nv.call("t2v_pool2x2_sum", dxv.data_ptr(), cin_p, dx.data_ptr(), cin_p, cfg.nimg, cfg.H, cfg.W, cin_p,
+                            nv.stream())
+                else:
+                    dx = dxv
+        # factor gradients, accumulated in place in the flat fp32 gradient buffer
+        launch_gemm(M=npad, N=e.rp, K=M, A=dy.data_ptr(), lda=_ld(dy), a_trans=1, B=t.data_ptr(), ldb=e.rp, b_trans=1,
+                    D=e.up_g.data_ptr(), ldd=e.rp, out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
+                    split_k=_split_k((npad + 127) // 128, M))
+        kw = cfg.taps() * cin_p
+        launch_gemm(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
+                    b_conv=1 if conv else 0, geom=cfg.fwd_geom(cin_p) if conv else None, D=e.down_g.data_ptr(), ldd=kw,
+                    out_mode=nv.OUT_F32_ATOMIC, split_k=_split_k((kw + 63) // 64, M))
+        return dx, None, None, None, None, drb, dres, None, None, None
+
+
+def lora_layer(x, w_base, b_base, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None):
+    return _LoraLayer.apply(x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, entry, float(scale))
+
+
 def conv_linear(x, weight, bias=None, cfg=LINEAR, rowbias=None, residual=None, alpha=1.0, drop_p=0.0, drop_seed=0):
     return _ConvLinear.apply(x, weight, bias, rowbias, residual, cfg, float(alpha), float(drop_p), int(drop_seed))
 
 
 # --------------------------------------------------------------------------- GroupNorm (+SiLU, +dropout)
+_gn_ws = {}
+
+
+def _gn_workspace(ndomains, G, device):
+    """Scratch for the fixed-order statistics reduction; one buffer per device, reused by every call on the stream
+    (stream order serialises the stats -> finalize pairs that use it)."""
+    need = int(nv.lib().t2v_gn_workspace_floats(ndomains, G))
+    buf = _gn_ws.get(device)
+    if buf is None or buf.numel() < need:
+        buf = _gn_ws[device] = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=device)
+    return buf
+
+
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, G, eps, silu, ndomains, drop_p, drop_seed):
@@ -292,9 +418,10 @@ class _GroupNorm(torch.autograd.Function):
         rows, Cc = x.shape
         rpd = rows // ndomains
         g32, b32 = _f32(gamma), _f32(beta)
-        sums = torch.zeros(ndomains * G * 2, dtype=torch.float32, device=x.device)
+        sums = torch.empty(ndomains * G * 2, dtype=torch.float32, device=x.device)
+        ws = _gn_workspace(ndomains, G, x.device)
         s = nv.stream()
-        nv.call("t2v_gn_stats", x.data_ptr(), _ld(x), ndomains, rpd, Cc, G, sums.data_ptr(), s)
+        nv.call("t2v_gn_stats", x.data_ptr(), _ld(x), ndomains, rpd, Cc, G, sums.data_ptr(), ws.data_ptr(), s)
         y = torch.empty(rows, Cc, dtype=BF16, device=x.device)
         nv.call("t2v_gn_apply", x.data_ptr(), _ld(x), y.data_ptr(), Cc, ndomains, rpd, Cc, G, sums.data_ptr(),
                 g32.data_ptr(), b32.data_ptr(), eps, int(silu), drop_p, drop_seed, s)
@@ -313,9 +440,11 @@ class _GroupNorm(torch.autograd.Function):
         want_pg = gamma.requires_grad or beta.requires_grad
         dgm = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         dbt = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
-        bsums = torch.zeros(ndomains * G * 2, dtype=torch.float32, device=x.device)
+        bsums = torch.empty(ndomains * G * 2, dtype=torch.float32, device=x.device)
+        ws = _gn_workspace(ndomains, G, x.device)
         nv.call("t2v_gn_bwd_stats", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ndomains, rpd, Cc, G, sums.data_ptr(),
-                g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, bsums.data_ptr(), nv.ptr(dgm), nv.ptr(dbt), s)
+                g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, bsums.data_ptr(), ws.data_ptr(), nv.ptr(dgm),
+                nv.ptr(dbt), s)
         dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
         nv.call("t2v_gn_bwd_apply", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, ndomains, rpd, Cc, G,
                 sums.data_ptr(), bsums.data_ptr(), g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, s)

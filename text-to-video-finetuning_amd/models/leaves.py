@@ -78,6 +78,13 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None):
     if base is None:
         base = getattr(mod, "conv", None)
     if base is not None and hasattr(mod, "lora_down") and hasattr(mod, "lora_up"):      # cloneofsimo wrapper
+        entry = getattr(mod, "_t2v_bank", None)
+        sel = getattr(mod, "selector", None)
+        if (entry is not None and _drop_p(getattr(mod, "dropout", None)) == 0.0 and not base.weight.requires_grad
+                and (base.bias is None or not base.bias.requires_grad) and (sel is None or isinstance(sel, nn.Identity))
+                and torch.is_grad_enabled()):
+            return F.lora_layer(x, base.weight, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry,
+                                float(mod.scale), rowbias, residual)
         y = F.conv_linear(x, base.weight, base.bias, cfg, rowbias, residual)
         t = F.conv_linear(x, mod.lora_down.weight, None, cfg)
         sel = getattr(mod, "selector", None)

@@ -1,0 +1,161 @@
+"""Native VAE encoder for `tensor_to_vae_latent` (reference: `train.py:339-347`, `handle_cache_latents :266-314`).
+
+`AutoencoderKL.encode(x).latent_dist.sample()` of diffusers restated over the HIP kernels: conv_in, 4
+DownEncoderBlock2D (2 resnets each, stride-2 pad-(0,1,0,1) downsample on the first three), mid block
+(resnet, single-head d=512 attention, resnet), GroupNorm+SiLU, conv_out, quant_conv, diagonal-Gaussian sample
+(SURVEY.md Appendix A.7).  Attribute names/state-dict keys follow diffusers (`encoder.down_blocks.i.resnets.j`, …).
+The d=512 attention is computed per frame with the batched GEMM (scores -> row softmax -> P V); it is <1 % of the
+encoder FLOPs.  Forward only: the VAE is frozen (`train.py:543`).
+"""
+import torch
+from torch import nn
+
+from .. import functional as F
+from .. import native as nv
+from ..functional import ConvCfg
+from .leaves import Downsample2D, ResnetBlock2D, Tok, run_layer
+from .modeling_utils import ModelMixinLite
+
+BF16 = torch.bfloat16
+
+
+class VaeAttention(nn.Module):
+    def __init__(self, channels, groups=32, eps=1e-6):
+        super().__init__()
+        self.channels = channels
+        self.group_norm = nn.GroupNorm(groups, channels, eps=eps, affine=True)
+        self.to_q = nn.Linear(channels, channels)
+        self.to_k = nn.Linear(channels, channels)
+        self.to_v = nn.Linear(channels, channels)
+        self.to_out = nn.ModuleList([nn.Linear(channels, channels), nn.Dropout(0.0)])
+
+    def forward(self, x):
+        n, S, Cc = x.n, x.h * x.w, x.C
+        a = F.group_norm(x.m, self.group_norm.weight, self.group_norm.bias, self.group_norm.num_groups,
+                         self.group_norm.eps, False, n)
+        q, k, v = run_layer(self.to_q, a), run_layer(self.to_k, a), run_layer(self.to_v, a)
+        Sp = F.ceil8(S)
+        scores = torch.empty(n * S, Sp, dtype=BF16, device=a.device)
+        F.launch_gemm(M=S, N=S, K=Cc, A=q.data_ptr(), lda=Cc, B=k.data_ptr(), ldb=Cc, D=scores.data_ptr(), ldd=Sp,
+                      alpha=float(Cc) ** -0.5, batch=n, strideA=S * Cc, strideB=S * Cc, strideD=S * Sp)
+        if Sp != S:
+            raise RuntimeError("t2v_amd: VAE attention needs H*W/64 to be a multiple of 8")
+        nv.call("t2v_softmax_rows", scores.data_ptr(), Sp, scores.data_ptr(), Sp, n * S, S, nv.stream())
+        o = torch.empty(n * S, Cc, dtype=BF16, device=a.device)
+        F.launch_gemm(M=S, N=Cc, K=S, A=scores.data_ptr(), lda=Sp, B=v.data_ptr(), ldb=Cc, b_trans=1, D=o.data_ptr(),
+                      ldd=Cc, batch=n, strideA=S * Sp, strideB=S * Cc, strideD=S * Cc)
+        return Tok(run_layer(self.to_out[0], o, residual=x.m), x.n, x.h, x.w)
+
+
+class DownEncoderBlock2D(nn.Module):
+    def __init__(self, cin, cout, num_layers=2, add_downsample=True, eps=1e-6, groups=32):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            ResnetBlock2D(in_channels=cin if i == 0 else cout, out_channels=cout, temb_channels=None, eps=eps,
+                          groups=groups) for i in range(num_layers)])
+        self.downsamplers = None
+        if add_downsample:
+            self.downsamplers = nn.ModuleList([Downsample2D(cout, use_conv=True, out_channels=cout, padding=0, name="op")])
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x, None)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                x = d(x)
+        return x
+
+
+class VaeMidBlock(nn.Module):
+    def __init__(self, c, eps=1e-6, groups=32):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_channels=c, out_channels=c, temb_channels=None, eps=eps,
+                                                    groups=groups) for _ in range(2)])
+        self.attentions = nn.ModuleList([VaeAttention(c, groups, eps)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x, None)), None)
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 groups=32):
+        super().__init__()
+        boc = block_out_channels
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList([])
+        cout = boc[0]
+        for i, c in enumerate(boc):
+            cin, cout = cout, c
+            self.down_blocks.append(DownEncoderBlock2D(cin, cout, layers_per_block, add_downsample=i != len(boc) - 1,
+                                                       groups=groups))
+        self.mid_block = VaeMidBlock(boc[-1], groups=groups)
+        self.conv_norm_out = nn.GroupNorm(groups, boc[-1], eps=1e-6)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(boc[-1], 2 * latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = Tok(run_layer(self.conv_in, x.m, ConvCfg.conv2d(x.n, x.h, x.w, 3, 1, 1)), x.n, x.h, x.w)
+        for b in self.down_blocks:
+            x = b(x)
+        x = self.mid_block(x)
+        a = F.group_norm(x.m, self.conv_norm_out.weight, self.conv_norm_out.bias, self.conv_norm_out.num_groups,
+                         self.conv_norm_out.eps, True, x.n)
+        return Tok(run_layer(self.conv_out, a, ConvCfg.conv2d(x.n, x.h, x.w, 3, 1, 1)), x.n, x.h, x.w)
+
+
+class DiagonalGaussianDistribution:
+    def __init__(self, mean, logvar):
+        self.mean = mean
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None, eps=None):
+        if eps is None:
+            eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * eps.to(self.mean.device, self.mean.dtype)
+
+    def mode(self):
+        return self.mean
+
+
+class _EncOut:
+    def __init__(self, dist):
+        self.latent_dist = dist
+
+
+class AutoencoderKL(nn.Module, ModelMixinLite):
+    """Encoder half of the SD VAE (the train step never decodes).  `encode(x).latent_dist.sample()` as in train.py:343."""
+
+    def __init__(self, in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
+                 layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215, **_):
+        super().__init__()
+        self.register_to_config(in_channels=in_channels, out_channels=out_channels, latent_channels=latent_channels,
+                                block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+                                norm_num_groups=norm_num_groups, scaling_factor=scaling_factor)
+        self.encoder = Encoder(in_channels, latent_channels, tuple(block_out_channels), layers_per_block, norm_num_groups)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+        self.use_slicing = False
+
+    def enable_slicing(self):   # train.py:280,678 — batching knob only, results unchanged
+        self.use_slicing = True
+
+    @torch.no_grad()
+    def encode(self, x, return_dict=True):
+        if not x.is_cuda:
+            raise RuntimeError("t2v_amd.AutoencoderKL runs on a ROCm device only (the CPU restatement is oracle/vae.py)")
+        lc = self.config.latent_channels
+        t = self.encoder(Tok.from_nchw(x))
+        m = run_layer(self.quant_conv, t.m, ConvCfg.conv2d(t.n, t.h, t.w, 1, 1, 0))
+        mom = Tok(m, t.n, t.h, t.w).to_nchw(2 * lc, torch.float32)
+        dist = DiagonalGaussianDistribution(mom[:, :lc], mom[:, lc:])
+        return _EncOut(dist) if return_dict else (dist,)
+
+
+def tensor_to_vae_latent(t, vae, eps=None):
+    """train.py:339-347; `eps` optionally injects the posterior noise (host-seeded parity runs)."""
+    b, f = t.shape[:2]
+    x = t.reshape((b * f,) + tuple(t.shape[2:]))
+    lat = vae.encode(x).latent_dist.sample(eps=eps)
+    lat = lat.reshape((b, f) + tuple(lat.shape[1:])).permute(0, 2, 1, 3, 4)
+    return lat * 0.18215

@@ -36,6 +36,9 @@ class Gemm(C.Structure):
         ("batch", c_int), ("strideA", c_ll), ("strideB", c_ll), ("strideD", c_ll), ("strideR", c_ll),
         ("split_k", c_int),
         ("drop_p", c_float), ("drop_seed", c_ull),
+        ("B2", c_void_p), ("ldb2", c_ll), ("n_split", c_int), ("D2", c_void_p), ("ldd2", c_ll),
+        ("b_tapflip", c_int),
+        ("workspace", c_void_p), ("workspace_bytes", C.c_size_t), ("ws_split", c_int),
     ]
 
 
@@ -72,11 +75,12 @@ SYMBOLS = {
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
     "t2v_smallconv": ([C.POINTER(SmallConv), c_void_p], c_int),
-    "t2v_gn_stats": ([c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "t2v_gn_workspace_floats": ([c_int, c_int], c_ll),
+    "t2v_gn_stats": ([c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "t2v_gn_apply": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                       c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_gn_bwd_stats": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                          c_float, c_int, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+                          c_float, c_int, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "t2v_gn_bwd_apply": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_float, c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_layernorm_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p],
@@ -85,6 +89,8 @@ SYMBOLS = {
                            c_void_p, c_void_p], c_int),
     "t2v_attn_fwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_attn_bwd": ([C.POINTER(Attn), c_void_p], c_int),
+    "t2v_softmax_rows": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_void_p], c_int),
+    "t2v_dropout_mask": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_geglu_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_geglu_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_silu_fwd": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),

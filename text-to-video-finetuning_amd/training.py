@@ -1,0 +1,206 @@
+"""The denoising train step on MI355X: the device-side equivalent of `train.py:720-836` (`finetune_unet`) and
+`train.py:848-879` (backward, global-norm clip, AdamW), plus the data-parallel gradient exchange the reference gets
+from accelerate/DDP (`train.py:661-667`).
+
+  * trainable tensors (LoRA factors, or any subset) are re-homed into ONE flat fp32 buffer; their `.grad`s are views of
+    one flat gradient buffer, so autograd accumulates straight into it, the DP exchange is a single RCCL all-reduce of
+    that buffer over xGMI, and clip + AdamW are two fused kernels (the reference builds one param group per tensor,
+    train.py:221-234);
+  * the two UNet passes of `train.py:814-834` are kept (loss = mse0 + mse1);
+  * `capture()` records forward+backward of a step into a HIP graph (static shapes) and replays it, removing the
+    ~10^4 Python-side launches from the critical path.
+"""
+import torch
+
+from . import native as nv
+from .models.vae import tensor_to_vae_latent
+from .schedulers import DDPMScheduler
+
+
+class _Mse(torch.autograd.Function):
+    """F.mse_loss(pred.float(), target.float()) (train.py:827) with its gradient produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        nv.require_cuda(pred, target)
+        pred = pred.contiguous().float()
+        target = target.contiguous().float()
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        nv.call("t2v_mse_fwd_bwd", pred.data_ptr(), target.data_ptr(), pred.numel(), loss.data_ptr(), dpred.data_ptr(),
+                1.0, nv.stream())
+        ctx.save_for_backward(dpred)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None
+
+
+def mse_loss(pred, target):
+    return _Mse.apply(pred, target)
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (train.py:238-249: betas (0.9,0.999), wd 1e-2, eps 1e-8) on one flat buffer.
+
+    Every trainable tensor is re-homed into `flat_p` (its `.grad` into `flat_g`).  If `model` is given, LoRA factors of
+    cloneofsimo-style wrappers are stored in GEMM layout (lora_bank.py) and a bf16 shadow `flat_p16` is kept, refreshed by
+    `refresh_bf16()` (one cast kernel per step)."""
+
+    def __init__(self, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0, model=None):
+        from . import lora_bank
+        seen, plist = set(), []
+        for p in params:
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                plist.append(p)
+        if not plist:
+            raise ValueError("FlatAdamW: no trainable parameters")
+        dev = plist[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdamW runs on a ROCm device only")
+        self.params = plist
+        self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
+        plans = lora_bank.plan(model)
+        sizes = []
+        for p in plist:
+            pl = plans.get(id(p))
+            k = (pl[0].down_numel if pl[1] == "down" else pl[0].up_numel) if pl else p.numel()
+            sizes.append((k + 7) // 8 * 8)                       # keep every slice 16-byte aligned in bf16
+        n = sum(sizes)
+        self.numel = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_p16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        off, offsets = 0, {}
+        for p, k in zip(plist, sizes):
+            pl = plans.get(id(p))
+            if pl:
+                view = lora_bank.param_view(self.flat_p[off:off + k], p, pl[0], pl[1])
+                gview = lora_bank.param_view(self.flat_g[off:off + k], p, pl[0], pl[1])
+            else:
+                view = self.flat_p[off:off + p.numel()].view(p.shape)
+                gview = self.flat_g[off:off + p.numel()].view(p.shape)
+            view.copy_(p.detach().float())
+            p.data = view
+            p.grad = gview
+            offsets[id(p)] = off
+            off += k
+        lora_bank.attach(plans, self.flat_p16, self.flat_g, offsets)
+        self.refresh_bf16()
+
+    def refresh_bf16(self):
+        nv.call("t2v_cast_f32_to_bf16", self.flat_p.data_ptr(), self.flat_p16.data_ptr(), self.numel, nv.stream())
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+
+    def grad_norm(self):
+        return self.sumsq.sqrt()
+
+    def step(self, grad_scale=1.0):
+        s = nv.stream()
+        self.sumsq.zero_()
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        if clip:
+            nv.call("t2v_sumsq", self.flat_g.data_ptr(), self.numel, self.sumsq.data_ptr(), s)
+        nv.call("t2v_adamw", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                self.sumsq.data_ptr() if clip else None, float(self.max_grad_norm or 0.0), float(grad_scale),
+                self.step_count.data_ptr(), s)
+
+
+class DenoiseTrainer:
+    """One optimisation step = VAE encode -> noise/add_noise -> 2x UNet forward -> eps-MSE -> backward ->
+    (RCCL all-reduce of the flat LoRA gradient) -> clip -> AdamW."""
+
+    def __init__(self, unet, vae, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
+                 scheduler=None, process_group=None, world_size=1):
+        self.unet, self.vae = unet, vae
+        self.scheduler = scheduler or DDPMScheduler()
+        self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet)
+        self.pg, self.world = process_group, world_size
+        self._graph = None
+        self._static = None
+
+    # ---- train.py:720-836
+    def loss_fn(self, batch):
+        if "latents" in batch:                       # cache_latents path (train.py:744)
+            latents = batch["latents"]
+        else:
+            latents = tensor_to_vae_latent(batch["pixel_values"], self.vae, batch.get("vae_eps"))
+        noise = batch["noise"] if "noise" in batch else torch.randn_like(latents)
+        bsz = latents.shape[0]
+        if "timesteps" in batch:
+            timesteps = batch["timesteps"]
+        else:
+            timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bsz,), device=latents.device).long()
+        noisy = self.scheduler.add_noise(latents, noise, timesteps)
+        ehs = batch["encoder_hidden_states"]
+        if self.scheduler.prediction_type == "epsilon":
+            target = noise
+        elif self.scheduler.prediction_type == "v_prediction":
+            target = self.scheduler.get_velocity(latents, noise, timesteps)
+        else:
+            raise ValueError(f"Unknown prediction type {self.scheduler.prediction_type}")
+        video_length = latents.shape[2]
+        losses = []
+        for i in range(2):                            # train.py:814: two passes, losses summed
+            pred = self.unet(noisy, timesteps, encoder_hidden_states=ehs).sample
+            losses.append(mse_loss(pred.float(), target.float()))
+            if video_length == 1 and i == 0:
+                break
+        return losses[0] if len(losses) == 1 else losses[0] + losses[1]
+
+    def _fwd_bwd(self, batch):
+        self.opt.refresh_bf16()            # bf16 copies of every LoRA factor for this step: one cast kernel
+        loss = self.loss_fn(batch)
+        loss.backward()
+        return loss.detach()
+
+    def _exchange_and_update(self):
+        from .parallel import allreduce_flat_grads
+        scale, _ = allreduce_flat_grads(self.opt.flat_g, self.world, self.pg)   # RCCL over xGMI: one flat buffer
+        self.opt.step(grad_scale=scale)
+
+    def train_step(self, batch):
+        self.opt.zero_grad()
+        loss = self._fwd_bwd(batch)
+        self._exchange_and_update()
+        return loss
+
+    # ---- HIP-graph replay of forward+backward (static shapes)
+    def capture(self, batch, warmup=2):
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.opt.zero_grad()
+                self._fwd_bwd(static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.opt.zero_grad()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_loss = self._fwd_bwd(static)
+        self._graph, self._static = g, static
+        return self
+
+    def replay_step(self, batch=None):
+        if self._graph is None:
+            raise RuntimeError("call capture() first")
+        if batch is not None:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self._static[k].copy_(v)
+        self.opt.zero_grad()
+        self._graph.replay()
+        self._exchange_and_update()
+        return self._static_loss
