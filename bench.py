@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--no-text-encoder", action="store_true", help="feed synthetic text states instead of running CLIP")
     return ap.parse_args()
 
 
@@ -70,10 +71,34 @@ def build_models(frames, lora_rank, device, seed):
     return unet, vae, trainable
 
 
-def synthetic_batch(frames, H, W, device, seed):
+def build_text_encoder(device):
+    """Random-init CLIP text tower in the ModelScope/OpenCLIP ViT-H shape (23 layers, d=1024, 16 heads, MLP 4096, 77 tokens;
+    SURVEY.md A.10), frozen, bf16.  It is adjacent to the hot path (§8f row 2, ~45 GFLOP of a 24 TFLOP step) and runs through
+    stock PyTorch-ROCm ops; it is inside the timed step so that no part of the reference's step is skipped."""
+    try:
+        from transformers import CLIPTextConfig, CLIPTextModel
+        cfg = CLIPTextConfig(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=23,
+                             num_attention_heads=16, max_position_embeddings=77, hidden_act="gelu", projection_dim=1024)
+        torch.manual_seed(2)
+        with torch.device(device):
+            te = CLIPTextModel(cfg)
+        return te.to(torch.bfloat16).eval().requires_grad_(False)
+    except Exception as e:   # noqa: BLE001
+        print(f"[bench] CLIP text encoder unavailable ({type(e).__name__}: {e}); using synthetic text states", file=sys.stderr)
+        return None
+
+
+def synthetic_batch(frames, H, W, device, seed, with_ids=False):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    return dict(pixel_values=(torch.rand(1, frames, 3, H, W, generator=g) * 2 - 1).to(device),
-                encoder_hidden_states=torch.randn(1, 77, 1024, generator=g).to(device))
+    b = dict(pixel_values=(torch.rand(1, frames, 3, H, W, generator=g) * 2 - 1).to(device))
+    if with_ids:   # utils/dataset.py:43-52: [BOS] + k tokens + [EOS] padding to 77, with the dataset's extra leading dim
+        ids = torch.full((1, 1, 77), 49407, dtype=torch.long)
+        ids[0, 0, 0] = 49406
+        ids[0, 0, 1:9] = torch.randint(0, 49406, (8,), generator=g)
+        b["prompt_ids"] = ids.to(device)
+    else:
+        b["encoder_hidden_states"] = torch.randn(1, 77, 1024, generator=g).to(device)
+    return b
 
 
 def gemm_roofline(trainer, batch):
@@ -159,16 +184,36 @@ def main():
     frames, H, W, r = CONFIGS[args.config]
 
     unet, vae, trainable = build_models(frames, r, dev, seed=0)            # same frozen weights on every rank
-    trainer = DenoiseTrainer(unet, vae, trainable, lr=5e-6, world_size=world)
+    text_encoder = None if args.no_text_encoder else build_text_encoder(dev)
+    trainer = DenoiseTrainer(unet, vae, trainable, lr=5e-6, world_size=world, text_encoder=text_encoder)
     if world > 1:
         from t2v_amd.parallel import broadcast_params
         broadcast_params(trainer.opt.flat_p)
-    batch = synthetic_batch(frames, H, W, dev, seed=1234 + rank)          # one clip per GPU: weak scaling
+    batch = synthetic_batch(frames, H, W, dev, seed=1234 + rank, with_ids=text_encoder is not None)   # one clip per GPU
 
     use_graph = not args.no_graph
+    text_mode = "clip-in-step" if text_encoder is not None else "synthetic"
     if use_graph:
-        trainer.capture(batch, warmup=1)
-        step = lambda: trainer.replay_step()
+        try:
+            trainer.capture(batch, warmup=1)
+        except Exception as e:   # noqa: BLE001  (a transformers op that cannot be captured: keep CLIP eager, outside the graph)
+            if text_encoder is None:
+                raise
+            print(f"[bench] capturing CLIP failed ({type(e).__name__}); running it eagerly before each replay", file=sys.stderr)
+            torch.cuda.synchronize()
+            text_mode = "clip-eager-before-replay"
+            ids = batch.pop("prompt_ids")
+            with torch.no_grad():
+                batch["encoder_hidden_states"] = text_encoder(ids[0])[0]
+            trainer.capture(batch, warmup=1)
+            _replay = trainer.replay_step
+
+            def step():
+                with torch.no_grad():
+                    trainer._static["encoder_hidden_states"].copy_(text_encoder(ids[0])[0])
+                return _replay()
+        else:
+            step = lambda: trainer.replay_step()
     else:
         step = lambda: trainer.train_step(batch)
     for _ in range(args.warmup):
@@ -212,7 +257,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: ModelScope-1.7B UNet3D + SD-VAE encode, {frames} frames @{H}x{W}, "
                                    f"LoRA r={r} on all 574 Linear/Conv layers, batch 1 clip/GPU, 2 UNet passes/step, "
-                                   f"dropout off (reference eval_train mode), text states synthetic (CLIP out of scope)",
+                                   f"dropout off (reference eval_train mode), text encoder: {text_mode}",
                        "global_batch": world, "parallelism": f"dp{world}", "graph_replay": use_graph,
                        "trainable_params": trainer.opt.numel, "final_loss": final_loss},
             "roofline": roof, "cpu_baseline": cpu,

@@ -105,3 +105,35 @@ def test_weight_preparation_layouts():
     assert (cfg.Ho, cfg.Wo) == (4, 4)
     bg = cfg.bwd_geom(16)
     assert (bg.Hv, bg.Wv, bg.Ho, bg.Wo, bg.py, bg.tdiv) == (4, 4, 8, 8, 1, 2)
+
+
+def test_lora_bank_layouts_are_gemm_layouts():
+    """lora_bank: the flat-buffer storage of every LoRA factor IS the layout the GEMM kernels consume
+    (down: [rp, taps, Cin_p] with K ordered (tap, c); up: [rp, Np]) while the Parameter keeps the module's shape."""
+    import t2v_amd.lora_bank as lb
+    from t2v_amd.utils import lora as L
+    torch.manual_seed(0)
+    mods = torch.nn.ModuleDict(dict(
+        lin=L.LoraInjectedLinear(24, 40, bias=True, r=4),
+        c2d=L.LoraInjectedConv2d(16, 24, 3, 1, 1, r=4),
+        c3d=L.LoraInjectedConv3d(16, 16, (3, 1, 1), (1, 0, 0), r=16)))
+    for m in mods.values():
+        torch.nn.init.normal_(m.lora_up.weight)
+    plans = lb.plan(mods)
+    assert len(plans) == 6
+    for name, m in mods.items():
+        for role, p in (("down", m.lora_down.weight), ("up", m.lora_up.weight)):
+            e, r, _ = plans[id(p)]
+            assert r == role
+            n = e.down_numel if role == "down" else e.up_numel
+            flat = torch.zeros(n)
+            view = lb.param_view(flat, p, e, role)
+            assert view.shape == p.shape
+            view.copy_(p.detach())
+            if role == "down":
+                f3 = flat.view(e.rp, e.taps, e.cin_p)
+                ref = p.detach().flatten(2).permute(0, 2, 1) if p.dim() > 2 else p.detach()[:, None, :]
+                assert torch.equal(f3[: e.r, :, : e.cin], ref) and f3[e.r:].abs().sum() == 0
+            else:
+                f2 = flat.view(e.rp, e.npad)
+                assert torch.equal(f2[: e.r, : e.n], p.detach().flatten(1).t()) and f2[e.r:].abs().sum() == 0

@@ -93,6 +93,8 @@ def test_lora_train_steps_match_oracle():
 
 
 def test_graph_replay_equals_eager():
+    """HIP-graph replay of forward+backward must reproduce the eager step: identical loss at identical parameters
+    (step 0, up to the fp32 atomics of the loss/weight-gradient reductions) and the same short trajectory."""
     from oracle.weights import synthetic_batch
     from t2v_amd.training import DenoiseTrainer
     _, _, dunet, dvae, _ = _build(r=4)
@@ -100,13 +102,15 @@ def test_graph_replay_equals_eager():
     p1 = [p for p in dunet.parameters() if p.requires_grad]
     p2 = [p for p in dunet2.parameters() if p.requires_grad]
     batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=7, text_dim=64).items()}
-    t1 = DenoiseTrainer(dunet, dvae, p1, lr=1e-3)
-    t2 = DenoiseTrainer(dunet2, dvae, p2, lr=1e-3)
+    t1 = DenoiseTrainer(dunet, dvae, p1, lr=1e-4)
+    t2 = DenoiseTrainer(dunet2, dvae, p2, lr=1e-4)
     t2.capture(batch, warmup=1)
     for i in range(3):
         l1 = t1.train_step(batch)
         l2 = t2.replay_step(batch)
         torch.cuda.synchronize()
-        print(f"step {i}: eager {l1.item():.6f} graph {l2.item():.6f} pdiff {(t1.opt.flat_p - t2.opt.flat_p).abs().max().item():.3e}")
-    assert abs(l1.item() - l2.item()) / abs(l1.item()) < 1e-3
+        rel = abs(l1.item() - l2.item()) / abs(l1.item())
+        print(f"step {i}: eager {l1.item():.6f} graph {l2.item():.6f} rel {rel:.2e} "
+              f"pdiff {(t1.opt.flat_p - t2.opt.flat_p).abs().max().item():.3e}")
+        assert rel < (1e-5 if i == 0 else 5e-3)      # later steps: AdamW's sign-like first updates amplify 1-ulp differences
     assert relerr(t2.opt.flat_p, t1.opt.flat_p) < 1e-2

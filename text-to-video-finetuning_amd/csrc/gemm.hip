@@ -14,7 +14,11 @@
 // hardware-transpose fragment reads for K-major operands, XCD-aware tile order (consecutive N tiles of one
 // M tile share an XCD/L2).
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -146,44 +150,50 @@ __device__ __forceinline__ void finish_chunk(const T2VGemm& p, float (&v)[8], lo
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void epilogue(const T2VGemm& p, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], unsigned char* smem,
                                          long long m0, int n0, int z, long long zoffD, long long zoffR) {
+  constexpr int NT = WM * WN * 64;
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int M = p.M, N = p.N;
-  float* sC = (float*)smem;   // BM x BN fp32 fits in the (now idle) staging buffers
+  float* sC = (float*)smem;   // (WM*32) x BN fp32 staging, one 32-row fragment band per pass (keeps LDS/WG small)
+  constexpr int CPR = BN / 8;
 #pragma unroll
-  for (int j = 0; j < FN; ++j)
+  for (int i = 0; i < FM; ++i) {
+    if (i > 0) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int rl = wr * (FM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         int cl = wc * (FN * 32) + j * 32 + (lane & 31);
         sC[rl * BN + cl] = acc[i][j][r];
       }
-  __syncthreads();
-  constexpr int CPR = BN / 8;
+    __syncthreads();
 #pragma unroll 1
-  for (int c = tid; c < BM * CPR; c += 256) {
-    const int rl = c / CPR, cc = c - rl * CPR;
-    const long long row = m0 + rl;
-    const int col = n0 + cc * 8;
-    if (row >= M || col >= N) continue;
-    float v[8];
-    {
-      const float4 a = *(const float4*)(sC + rl * BN + cc * 8);
-      const float4 b = *(const float4*)(sC + rl * BN + cc * 8 + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    for (int c = tid; c < WM * 32 * CPR; c += NT) {
+      const int rl = c / CPR, cc = c - rl * CPR;
+      const long long row = m0 + (rl >> 5) * (FM * 32) + i * 32 + (rl & 31);
+      const int col = n0 + cc * 8;
+      if (row >= M || col >= N) continue;
+      float v[8];
+      {
+        const float4 a = *(const float4*)(sC + rl * BN + cc * 8);
+        const float4 b = *(const float4*)(sC + rl * BN + cc * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+      if (p.ws_split > 1) {      // split-K partial: plain store into this split's slice (summed in fixed order by the finalize pass)
+        float* wp = (float*)p.workspace + ((long long)z * M + row) * (long long)N + col;
+        const int nvv = min(8, N - col);
+        if (nvv == 8 && (N & 3) == 0) {
+          *(float4*)wp = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          for (int e = 0; e < nvv; ++e) wp[e] = v[e];
+        }
+        continue;
+      }
+      finish_chunk(p, v, row, col, z, zoffD, zoffR);
     }
-    if (p.ws_split > 1) {      // split-K partial: raw accumulate into the fp32 workspace, epilogue runs in the finalize pass
-      float* wp = (float*)p.workspace + row * (long long)N + col;
-      const int nvv = min(8, N - col);
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (e < nvv) atomicAdd(wp + e, v[e]);
-      continue;
-    }
-    finish_chunk(p, v, row, col, z, zoffD, zoffR);
   }
 }
 
@@ -201,11 +211,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // single prefetch.  LDS image is lane-linear (what the DMA writes); the XOR swizzle is applied to the per-lane
 // SOURCE chunk and to the fragment reads (same involution).  Conv zero padding / edge rows read a zero page.
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_kernel_dma(const T2VGemm p) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int NCA = BM / 32, NCB = BN / 32, LPT = NCA + NCB;
+  constexpr int NT = WM * WN * 64, RPP = NT / 8;      // threads, tile rows covered per 16-byte-chunk pass
+  constexpr int NCA = BM / RPP, NCB = BN / RPP, LPT = NCA + NCB;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && RPP % 16 == 0, "tile/threads mismatch");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int M = p.M, N = p.N;
@@ -239,27 +251,42 @@ __global__ __launch_bounds__(256) void gemm_kernel_dma(const T2VGemm p) {
   const bf16_t* zp = (const bf16_t*)g_zero_page;
 
   // chunk c = tid + 256*i of a tile sits at LDS byte c*16 (row c>>3, slot c&7) and holds source chunk slot^swz(row)
-  const int kc = (tid & 7) ^ ((tid >> 4) & 7);          // (row>>1)&7 is the same for all i: rows differ by 32*i
-  Pos posA[NCA];
+  const int kc = (tid & 7) ^ ((tid >> 4) & 7);          // (row>>1)&7 is the same for all i: rows differ by multiples of 16
+  // conv gather state: per row the window origin (n, vy0, vx0); per thread the running (k index, channel, ky, kx) of its
+  // chunk — advanced incrementally every K step, so the steady-state loop has no integer division
+  int rn[NCA], rvy[NCA], rvx[NCA];
   const bf16_t* arow[NCA];
   bool aok[NCA];
+  const bool is_conv = p.a_mode == T2V_A_CONV;
+  const int Hr = g.Hv >> g.up, Wr = g.Wv >> g.up;
 #pragma unroll
   for (int i = 0; i < NCA; ++i) {
-    long long m = m0 + (tid >> 3) + 32 * i;
+    long long m = m0 + (tid >> 3) + RPP * i;
     aok[i] = m < M;
-    if (p.a_mode == T2V_A_CONV) {
-      posA[i] = decompose(m, M, g);
+    if (is_conv) {
+      Pos ps = decompose(m, M, g);
+      rn[i] = ps.n * Hr;
+      rvy[i] = ps.oy * g.sy - g.py;
+      rvx[i] = ps.ox * g.sx - g.px;
       arow[i] = A;
     } else {
-      posA[i] = Pos{0, 0, 0, 0};
+      rn[i] = rvy[i] = rvx[i] = 0;
       arow[i] = A + (aok[i] ? m : 0) * p.lda;
     }
+  }
+  int ck = 0, cky = 0, ckx = 0;                          // channel offset / tap row / tap col of this thread's chunk
+  if (is_conv) {
+    const int kidx0 = kbeg + kc * 8;
+    const int tap0 = kidx0 / g.C;
+    ck = kidx0 - tap0 * g.C;
+    cky = tap0 / g.KW;
+    ckx = tap0 - cky * g.KW;
   }
   const bf16_t* brow[NCB];
   bool bok[NCB];
 #pragma unroll
   for (int i = 0; i < NCB; ++i) {
-    int n = n0 + (tid >> 3) + 32 * i;
+    int n = n0 + (tid >> 3) + RPP * i;
     bok[i] = n < N;
     if (p.n_split > 0 && n >= p.n_split)
       brow[i] = (const bf16_t*)p.B2 + (long long)(bok[i] ? n - p.n_split : 0) * p.ldb2;
@@ -272,30 +299,43 @@ __global__ __launch_bounds__(256) void gemm_kernel_dma(const T2VGemm p) {
     unsigned char* sB = sA + A_BYTES;
     const int kidx = k0 + kc * 8;
     const bool kok = kidx < kend;
-    if (p.a_mode == T2V_A_CONV) {
-      const int tap = kidx / g.C;
-      const int c = kidx - tap * g.C;
+    if (is_conv) {
 #pragma unroll
       for (int i = 0; i < NCA; ++i) {
-        bool v;
-        long long sr = src_row(posA[i], tap, g, v);
-        const bf16_t* src = (v && kok) ? A + sr * p.lda + c : zp;
+        int vy = rvy[i] + cky, vx = rvx[i] + ckx;
+        bool v = aok[i] && kok;
+        if (g.tdiv == 2) {
+          v = v && (((vy | vx) & 1) == 0);
+          vy >>= 1;
+          vx >>= 1;
+        }
+        v = v && ((unsigned)vy < (unsigned)g.Hv) && ((unsigned)vx < (unsigned)g.Wv);
+        const long long sr = (long long)(rn[i] + (vy >> g.up)) * Wr + (vx >> g.up);
+        const bf16_t* src = v ? A + sr * p.lda + ck : zp;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sA + (tid + 256 * i) * 16), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(sA + (tid + NT * i) * 16), 16, 0, 0);
+      }
+      ck += BK;                                           // next K step of this thread's chunk
+      while (ck >= g.C) {
+        ck -= g.C;
+        if (++ckx == g.KW) {
+          ckx = 0;
+          ++cky;
+        }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NCA; ++i) {
         const bf16_t* src = (aok[i] && kok) ? arow[i] + kidx : zp;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sA + (tid + 256 * i) * 16), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(sA + (tid + NT * i) * 16), 16, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const bf16_t* src = (bok[i] && kok) ? brow[i] + kidx : zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sB + (tid + 256 * i) * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sB + (tid + NT * i) * 16), 16, 0, 0);
     }
   };
 
@@ -621,7 +661,8 @@ bool g_force_regstage = false;   // T2V_GEMM_REGSTAGE=1: A/B the register-staged
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_dma(const T2VGemm& p, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BK * 2;
-  constexpr int SMEM = RING > BM * BN * 4 ? RING : BM * BN * 4;
+  constexpr int EPI = WM * 32 * BN * 4;
+  constexpr int SMEM = RING > EPI ? RING : EPI;
   auto kern = gemm_kernel_dma<BM, BN, WM, WN, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -630,77 +671,201 @@ int launch_dma(const T2VGemm& p, hipStream_t s) {
   }
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, p.ws_split > 1 ? p.ws_split : (p.batch > 1 ? p.batch : 1));
-  hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), SMEM, s, p);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_f32_kernel(float4* p, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // finalize pass of a workspace split-K launch: full epilogue over the fp32 partial sums
-__global__ __launch_bounds__(256) void gemm_finalize_kernel(const T2VGemm p) {
+__global__ __launch_bounds__(256) void gemm_finalize_kernel(const T2VGemm p, int nsplit) {
   const int cpr = (p.N + 7) / 8;
   const long long n = (long long)p.M * cpr;
   for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < n; c += (long long)gridDim.x * 256) {
     const long long row = c / cpr;
     const int col = (int)(c - row * cpr) * 8;
-    const float* wp = (const float*)p.workspace + row * (long long)p.N + col;
     float v[8];
     const int nv = min(8, p.N - col);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = e < nv ? wp[e] : 0.f;
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int zz = 0; zz < nsplit; ++zz) {
+      const float* wp = (const float*)p.workspace + ((long long)zz * p.M + row) * (long long)p.N + col;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nv) v[e] += wp[e];
+    }
     finish_chunk(p, v, row, col, 0, 0, 0);
   }
 }
 
 // pick the tile that minimises (waves of workgroups) x (tile cost); ~2 workgroups resident per CU
+// ---- NN (LDS-DMA) launch configurations: tile x ring depth x workspace split-K -------------------------------------
+struct DmaCfg {
+  int tile;    // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32, 4: 256x128 (8 waves)
+  int stages;  // 2 = occupancy variant, 0 = deep ring (3 for 128x128, 4 otherwise)
+  int split;   // 1 = none, >1 = split K through the fp32 workspace + finalize pass
+};
+
+int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
+  T2VGemm q = p;
+  int split = c.split;
+  if (split > 1) {
+    const int per = ((p.K + split - 1) / split + BK - 1) / BK * BK;
+    split = (p.K + per - 1) / per;              // every split slice is written (no empty K ranges)
+  }
+  q.ws_split = split > 1 ? split : 0;
+  int rc;
+  const bool s2 = c.stages == 2;
+  switch (c.tile) {
+    case 0: rc = s2 ? launch_dma<128, 128, 2, 2, 2>(q, s) : launch_dma<128, 128, 2, 2, 3>(q, s); break;
+    case 1: rc = s2 ? launch_dma<128, 64, 2, 2, 2>(q, s) : launch_dma<128, 64, 2, 2, 4>(q, s); break;
+    case 2: rc = s2 ? launch_dma<64, 64, 2, 2, 2>(q, s) : launch_dma<64, 64, 2, 2, 4>(q, s); break;
+    case 4: rc = s2 ? launch_dma<256, 128, 4, 2, 2>(q, s) : launch_dma<256, 128, 4, 2, 3>(q, s); break;
+    default: rc = s2 ? launch_dma<128, 32, 4, 1, 2>(q, s) : launch_dma<128, 32, 4, 1, 4>(q, s); break;
+  }
+  if (rc) return rc;
+  if (split > 1) {
+    q.ws_split = 1;
+    long long nchunk = (long long)p.M * ((p.N + 7) / 8);
+    hipLaunchKernelGGL(gemm_finalize_kernel, dim3((int)std::min<long long>((nchunk + 255) / 256, 4096)), dim3(256), 0, s, q, split);
+    T2V_CHECK_LAUNCH();
+  }
+  return T2V_OK;
+}
+
+DmaCfg heuristic_cfg(const T2VGemm& p) {
+  const bool shortk = p.K <= 640;
+  const bool can_split = p.workspace && p.batch <= 1 && p.out_mode == T2V_OUT_BF16;
+  if (can_split) {
+    int bm = 64, bn = 64;
+    if (p.N <= 32) { bm = 128; bn = 32; }
+    long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    long long split = std::min<long long>(std::min<long long>(384 / std::max<long long>(1, tiles), p.K / 256), 32);
+    split = std::min<long long>(split, (long long)(p.workspace_bytes / ((size_t)p.M * p.N * 4 + 16)));
+    if (tiles <= 96 && split >= 2) return DmaCfg{p.N <= 32 ? 3 : 2, 0, (int)split};
+  }
+  if (p.N <= 32) return DmaCfg{3, shortk ? 2 : 0, 1};
+  const long long zdim = p.batch > 1 ? p.batch : 1;
+  auto cost = [&](int bm, int bn, double eff) {
+    long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zdim;
+    long long waves = (tiles + 511) / 512;
+    return (double)waves * bm * bn / eff;
+  };
+  double c0 = cost(128, 128, 1.0), c1 = cost(128, 64, 0.8), c2 = cost(64, 64, 0.55);
+  int tile = (c0 <= c1 && c0 <= c2) ? 0 : (c1 <= c2 ? 1 : 2);
+  return DmaCfg{tile, shortk ? 2 : 0, 1};
+}
+
+// First-use autotuning (eager launches only; never while a stream capture is active): every candidate is timed
+// once with HIP events on the caller's stream and the winner is cached per problem signature.
+struct TuneKey {
+  int M, N, K, a_mode, n_split, out_mode, has_res, batch, KH, KW, sy, tdiv, up, C;
+  bool operator==(const TuneKey& o) const { return memcmp(this, &o, sizeof(TuneKey)) == 0; }
+};
+struct TuneHash {
+  size_t operator()(const TuneKey& k) const {
+    const int* w = (const int*)&k;
+    size_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(TuneKey) / sizeof(int); ++i) h = (h ^ (size_t)w[i]) * 1099511628211ull;
+    return h;
+  }
+};
+std::unordered_map<TuneKey, DmaCfg, TuneHash> g_tuned;
+std::mutex g_tune_mu;
+int g_autotune = -1;
+
+DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
+  if (g_autotune < 0) {
+    const char* e = getenv("T2V_GEMM_AUTOTUNE");
+    g_autotune = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!g_autotune) return heuristic_cfg(p);
+  TuneKey key;
+  memset(&key, 0, sizeof(key));
+  key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = p.n_split > 0; key.out_mode = p.out_mode;
+  key.has_res = p.R != nullptr; key.batch = p.batch > 1 ? p.batch : 1;
+  if (p.a_mode == T2V_A_CONV) { key.KH = p.geom.KH; key.KW = p.geom.KW; key.sy = p.geom.sy; key.tdiv = p.geom.tdiv; key.up = p.geom.up; key.C = p.geom.C; }
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) return it->second;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return heuristic_cfg(p);
+  // candidates
+  std::vector<DmaCfg> cand;
+  const bool can_split = p.workspace && p.batch <= 1 && p.out_mode == T2V_OUT_BF16;
+  const int tiles_lo = p.N <= 32 ? 3 : 0, tiles_hi = p.N <= 32 ? 3 : 2;
+  std::vector<int> tl;
+  for (int t = tiles_lo; t <= tiles_hi; ++t) tl.push_back(t);
+  if (p.N > 64 && (long long)p.M * p.N >= (long long)256 * 128 * 128) tl.push_back(4);   // big outputs: 8-wave 256x128 tile
+  for (int t : tl) {
+    static const int BMs[5] = {128, 128, 64, 128, 256}, BNs[5] = {128, 64, 64, 32, 128};
+    if (t < 3 && p.N <= 64 && BNs[t] > 64) continue;
+    long long tiles = (long long)((p.M + BMs[t] - 1) / BMs[t]) * ((p.N + BNs[t] - 1) / BNs[t]);
+    for (int st : {0, 2}) {
+      cand.push_back(DmaCfg{t, st, 1});
+      if (can_split && st == 0) {
+        for (int sp : {2, 4, 8, 16}) {
+          if (p.K / sp < 256 || tiles * sp > 2048) continue;
+          if ((size_t)p.M * p.N * 4 * sp + 16 > p.workspace_bytes) continue;
+          cand.push_back(DmaCfg{t, st, sp});
+        }
+      }
+    }
+  }
+  T2VGemm q = p;
+  if (q.R == q.D) q.R = nullptr;       // in-place accumulation must not be applied once per timing run
+  q.drop_p = 0.f;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  DmaCfg best = heuristic_cfg(p);
+  float best_ms = 1e30f;
+  for (const DmaCfg& c : cand) {
+    if (launch_dma_cfg(q, c, s) != T2V_OK) continue;      // warm (also sets the LDS attribute)
+    hipEventRecord(e0, s);
+    launch_dma_cfg(q, c, s);
+    launch_dma_cfg(q, c, s);
+    hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) continue;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best_ms) { best_ms = ms; best = c; }
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  (void)hipGetLastError();
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[key] = best;
+  }
+  if (getenv("T2V_GEMM_TUNE_LOG"))
+    fprintf(stderr, "[t2v tune] M=%d N=%d K=%d conv=%d -> tile %d stages %d split %d (%.1f us)\n", p.M, p.N, p.K, p.a_mode, best.tile,
+            best.stages, best.split, best_ms * 500.f);
+  return best;
+}
+
 template <bool AT, bool BT>
 int dispatch(const T2VGemm& p, hipStream_t s) {
+  constexpr bool DMA = !AT && !BT;
+  if constexpr (DMA) {
+    if (p.split_k <= 1 && !g_force_regstage) return launch_dma_cfg(p, pick_cfg(p, s), s);
+  }
   const long long zdim = p.split_k > 1 ? p.split_k : (p.batch > 1 ? p.batch : 1);
   auto cost = [&](int bm, int bn, double eff) {
     long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zdim;
     long long waves = (tiles + 511) / 512;
     return (double)waves * bm * bn / eff;
   };
-  constexpr bool DMA = !AT && !BT;
-  const bool dma = DMA && p.split_k <= 1 && !g_force_regstage;
-  if constexpr (DMA) {
-    // deep-K, few-tile launches (the 4x4/8x8-resolution layers at batch 1, LoRA dt = dy U): split K across workgroups
-    // through the caller's fp32 workspace, then run the epilogue in a finalize pass
-    if (dma && p.ws_split == 0 && p.workspace && p.batch <= 1 && p.out_mode == T2V_OUT_BF16) {
-      int bm = 64, bn = 64;
-      if (p.N <= 32) { bm = 128; bn = 32; }
-      long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-      int split = (int)std::min<long long>(std::min<long long>(384 / std::max<long long>(1, tiles), p.K / 256), 32);
-      if (tiles <= 96 && split >= 2 && (size_t)p.M * p.N * 4 <= p.workspace_bytes) {
-        T2VGemm q = p;
-        q.ws_split = split;
-        if (hipMemsetAsync(p.workspace, 0, (size_t)p.M * p.N * 4, s) != hipSuccess) {
-          t2v_set_error("t2v_gemm: workspace memset failed");
-          return T2V_ELAUNCH;
-        }
-        int rc = (p.N <= 32) ? launch_dma<128, 32, 4, 1, 4>(q, s) : launch_dma<64, 64, 2, 2, 4>(q, s);
-        if (rc) return rc;
-        q.ws_split = 1;
-        long long nchunk = (long long)p.M * ((p.N + 7) / 8);
-        hipLaunchKernelGGL(gemm_finalize_kernel, dim3((int)std::min<long long>((nchunk + 255) / 256, 4096)), dim3(256), 0, s, q);
-        T2V_CHECK_LAUNCH();
-        return T2V_OK;
-      }
-    }
-  }
-  if (p.N <= 32) {   // skinny outputs (LoRA rank): HBM-bound on A
-    if constexpr (DMA) { if (dma) return launch_dma<128, 32, 4, 1, 4>(p, s); }
-    return launch<128, 32, 4, 1, AT, BT>(p, s);
-  }
+  if (p.N <= 32) return launch<128, 32, 4, 1, AT, BT>(p, s);   // skinny outputs (LoRA rank): HBM-bound on A
   double c0 = cost(128, 128, 1.0), c1 = cost(128, 64, 0.8), c2 = cost(64, 64, 0.55);
-  if (c0 <= c1 && c0 <= c2) {
-    if constexpr (DMA) { if (dma) return launch_dma<128, 128, 2, 2, 3>(p, s); }
-    return launch<128, 128, 2, 2, AT, BT>(p, s);
-  }
-  if (c1 <= c2) {
-    if constexpr (DMA) { if (dma) return launch_dma<128, 64, 2, 2, 4>(p, s); }
-    return launch<128, 64, 2, 2, AT, BT>(p, s);
-  }
-  if constexpr (DMA) { if (dma) return launch_dma<64, 64, 2, 2, 4>(p, s); }
+  if (c0 <= c1 && c0 <= c2) return launch<128, 128, 2, 2, AT, BT>(p, s);
+  if (c1 <= c2) return launch<128, 64, 2, 2, AT, BT>(p, s);
   return launch<64, 64, 2, 2, AT, BT>(p, s);
 }
 

@@ -119,14 +119,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   if (tid < 2 * G) partial[(((long long)d * gridDim.x + blockIdx.x) * G) * 2 + tid] = gacc;
 }
 
-// sums[d][g][w] = sum over splits (fixed order)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nsplit, int G2) {
-  const int d = blockIdx.x;
-  for (int t = threadIdx.x; t < G2; t += blockDim.x) {
-    float a = 0.f;
-    for (int s = 0; s < nsplit; ++s) a += partial[((long long)d * nsplit + s) * G2 + t];
-    sums[(long long)d * G2 + t] = a;
-  }
+// sums[d][g][w] = sum over splits: one wave per output, lanes = splits, fixed butterfly order (bit-reproducible)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nsplit,
+                                                           int G2, int nout) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);      // output index = d * G2 + t
+  if (o >= nout) return;
+  const int d = o / G2, t = o - d * G2;
+  float v = lane < nsplit ? partial[((long long)d * nsplit + lane) * G2 + t] : 0.f;   // nsplit <= GN_MAX_SPLIT = 64
+  v = wave_sum(v);
+  if (lane == 0) sums[o] = v;
 }
 
 // ------------------------------------------------------------------ GroupNorm apply (fwd) / dx (bwd)
@@ -343,7 +345,8 @@ extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows
   hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0,
                      rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, workspace, nullptr, nullptr);
   T2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ndomains), dim3(64), 0, (hipStream_t)stream, workspace, sums, ns, 2 * G);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((ndomains * 2 * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, sums, ns, 2 * G,
+                     ndomains * 2 * G);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -375,7 +378,8 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
   hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
                      lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, workspace, dgamma, dbeta);
   T2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ndomains), dim3(64), 0, (hipStream_t)stream, workspace, bsums, ns, 2 * G);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((ndomains * 2 * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, bsums, ns, 2 * G,
+                     ndomains * 2 * G);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

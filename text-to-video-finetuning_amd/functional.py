@@ -10,6 +10,7 @@ nn.Linear / nn.Conv2d / nn.Conv3d forward+backward, F.group_norm(+silu), F.layer
 F.scaled_dot_product_attention (AttnProcessor2_0, train.py:138-139), GEGLU, SiLU.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -178,7 +179,7 @@ def _gemm_workspace():
     dev = torch.cuda.current_device()
     buf = _gemm_ws.get(dev)
     if buf is None:
-        buf = _gemm_ws[dev] = torch.empty(8 << 20, dtype=torch.float32, device=f"cuda:{dev}")   # 32 MB
+        buf = _gemm_ws[dev] = torch.empty(16 << 20, dtype=torch.float32, device=f"cuda:{dev}")   # 64 MB
     return buf
 
 
@@ -300,6 +301,25 @@ def _unprep_weight_grad(dwp, weight, cfg):
     return gw.to(weight.dtype).contiguous()
 
 
+# Factor-gradient launches (dU, dD) feed only the flat gradient buffer, i.e. they are off the critical path of
+# backward: they are issued on a side stream (forked after dt, joined once before the optimizer) so that they overlap the
+# latency-bound main chain.  Inside a HIP-graph capture this becomes a parallel branch of the graph.
+_side = {"stream": None, "refs": [], "enabled": os.environ.get("T2V_WGRAD_STREAM", "1") != "0"}
+
+
+def _side_stream():
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    return _side["stream"]
+
+
+def join_side_stream():
+    """Make the current stream wait for every factor-gradient launch issued so far; release their operand references."""
+    if _side["stream"] is not None and _side["refs"]:
+        torch.cuda.current_stream().wait_stream(_side["stream"])
+    _side["refs"].clear()
+
+
 class _LoraLayer(torch.autograd.Function):
     """One LoRA-wrapped layer: y = base(x) + scale * up(down(x)) (utils/lora.py:57-62,134-139,211-216, dropout off /
     identity selector) with the factors living in the trainer's flat buffers (lora_bank.py):
@@ -331,8 +351,8 @@ class _LoraLayer(torch.autograd.Function):
                     rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
                     R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
                     B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
-        launch_gemm(M=M, N=npad, K=e.rp, A=t.data_ptr(), lda=e.rp, B=e.up_w16.data_ptr(), ldb=e.rp, D=y.data_ptr(), ldd=npad,
-                    R=y.data_ptr(), ldr=npad, alpha=scale)
+        launch_gemm(M=M, N=npad, K=e.rp, A=t.data_ptr(), lda=e.rp, B=e.up_w16.data_ptr(), ldb=npad, b_trans=1, D=y.data_ptr(),
+                    ldd=npad, R=y.data_ptr(), ldr=npad, alpha=scale)
         ctx.cfg, ctx.e, ctx.scale = cfg, e, scale
         ctx.has = (rowbias is not None, residual is not None)
         ctx.save_for_backward(x, t, w_base, rowbias)
@@ -350,20 +370,24 @@ class _LoraLayer(torch.autograd.Function):
         drb = None
         if has_rb:
             drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
-        dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)
-        launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=e.rp, b_trans=1,
-                    D=dt.data_ptr(), ldd=e.rp, alpha=scale)
+        dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)      # dt = dy U (unscaled; `scale` is applied by its consumers)
         dx = None
         cin_p = e.cin_p
-        if ctx.needs_input_grad[0]:
+        need_dx = ctx.needs_input_grad[0]
+        if need_dx and not conv:
+            # linear: [dx | dt] = dy [W^T | U] in ONE launch (dt rides as rp extra output columns)
             wb = prepared_weight(w_base, "bwd")
-            if not conv:
-                dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
-                launch_gemm(M=M, N=cin_p, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
-                            D=dx.data_ptr(), ldd=cin_p)
-                launch_gemm(M=M, N=cin_p, K=e.rp, A=dt.data_ptr(), lda=e.rp, B=e.down_w16.data_ptr(), ldb=cin_p, b_trans=1,
-                            D=dx.data_ptr(), ldd=cin_p, R=dx.data_ptr(), ldr=cin_p)
-            else:
+            dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+            launch_gemm(M=M, N=cin_p + e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
+                        D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=npad, n_split=cin_p, D2=dt.data_ptr(),
+                        ldd2=e.rp)
+            launch_gemm(M=M, N=cin_p, K=e.rp, A=dt.data_ptr(), lda=e.rp, B=e.down_w16.data_ptr(), ldb=cin_p, b_trans=1,
+                        D=dx.data_ptr(), ldd=cin_p, R=dx.data_ptr(), ldr=cin_p, alpha=scale)
+        else:
+            launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=npad, D=dt.data_ptr(),
+                        ldd=e.rp)
+            if need_dx:
+                wb = prepared_weight(w_base, "bwd")
                 Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
                 Mi = cfg.nimg * Hv * Wv
                 dxv = torch.empty(Mi, cin_p, dtype=BF16, device=dy.device)
@@ -371,21 +395,32 @@ class _LoraLayer(torch.autograd.Function):
                             D=dxv.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(npad))
                 launch_gemm(M=Mi, N=cin_p, K=cfg.taps() * e.rp, A=dt.data_ptr(), lda=e.rp, B=e.down_w16.data_ptr(),
                             ldb=cfg.taps() * cin_p, b_trans=1, b_tapflip=1, D=dxv.data_ptr(), ldd=cin_p, R=dxv.data_ptr(),
-                            ldr=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(e.rp))
+                            ldr=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(e.rp), alpha=scale)
                 if cfg.up:
                     dx = torch.empty(cfg.nimg * cfg.H * cfg.W, cin_p, dtype=BF16, device=dy.device)
                     nv.call("t2v_pool2x2_sum", dxv.data_ptr(), cin_p, dx.data_ptr(), cin_p, cfg.nimg, cfg.H, cfg.W, cin_p,
                             nv.stream())
                 else:
                     dx = dxv
-        # factor gradients, accumulated in place in the flat fp32 gradient buffer
-        launch_gemm(M=npad, N=e.rp, K=M, A=dy.data_ptr(), lda=_ld(dy), a_trans=1, B=t.data_ptr(), ldb=e.rp, b_trans=1,
-                    D=e.up_g.data_ptr(), ldd=e.rp, out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
-                    split_k=_split_k((npad + 127) // 128, M))
+        # factor gradients, accumulated in place in the flat fp32 gradient buffer (side stream: see _side above)
         kw = cfg.taps() * cin_p
-        launch_gemm(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
-                    b_conv=1 if conv else 0, geom=cfg.fwd_geom(cin_p) if conv else None, D=e.down_g.data_ptr(), ldd=kw,
-                    out_mode=nv.OUT_F32_ATOMIC, split_k=_split_k((kw + 63) // 64, M))
+
+        def wgrads():
+            launch_gemm(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy.data_ptr(), ldb=_ld(dy), b_trans=1,
+                        D=e.up_g.data_ptr(), ldd=npad, out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
+                        split_k=_split_k((npad + 63) // 64, M))
+            launch_gemm(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
+                        b_conv=1 if conv else 0, geom=cfg.fwd_geom(cin_p) if conv else None, D=e.down_g.data_ptr(), ldd=kw,
+                        out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M))
+
+        if _side["enabled"]:
+            side = _side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                wgrads()
+            _side["refs"].append((dy, t, dt, x))      # keep operands alive until join_side_stream()
+        else:
+            wgrads()
         return dx, None, None, None, None, drb, dres, None, None, None
 
 

@@ -3,7 +3,8 @@
 The reference trains `lora_down` / `lora_up` of every wrapped layer (utils/lora.py:46-62,97-139,179-216).  Here every
 factor is stored in the flat fp32 parameter buffer DIRECTLY in the layout the GEMM kernels consume
   down  [rp, taps, Cin_p]   (K ordered (tap, c); the Parameter is a permuted, sliced VIEW with the module's shape)
-  up    [Np, rp]
+  up    [rp, Np]            (transposed: the backward `dt = dy U` reads it as a plain [N, K] weight and rides in the
+                             base layer's backward-data launch; the forward `y += s t U^T` reads it K-major)
 (rp / Np / Cin_p = sizes rounded up to 8, zero padded), so that
   * one cast kernel per step refreshes the bf16 copies of ALL factors (no per-layer permute/cast launches),
   * weight gradients are accumulated by the TN GEMM straight into the flat fp32 gradient buffer (no per-layer
@@ -70,7 +71,7 @@ def param_view(flat_slice, p, entry, role):
                 flat_slice.view(entry.rp, p.shape[2], p.shape[3], entry.cin_p)[: entry.r, :, :, : entry.cin].permute(0, 3, 1, 2)
         v = s3.permute(0, 2, 1)
         return v[:, :, :, None, None]
-    s2 = flat_slice.view(entry.npad, entry.rp)[: entry.n, : entry.r]
+    s2 = flat_slice.view(entry.rp, entry.npad)[: entry.r, : entry.n].t()
     for _ in range(p.dim() - 2):
         s2 = s2.unsqueeze(-1)
     return s2
@@ -89,8 +90,8 @@ def attach(plans, flat_p16, flat_g, offsets):
             e.down_g = flat_g[off: off + e.down_numel].view(e.rp, e.taps * e.cin_p)
         else:
             e.up_off = off
-            e.up_w16 = flat_p16[off: off + e.up_numel].view(e.npad, e.rp)
-            e.up_g = flat_g[off: off + e.up_numel].view(e.npad, e.rp)
+            e.up_w16 = flat_p16[off: off + e.up_numel].view(e.rp, e.npad)
+            e.up_g = flat_g[off: off + e.up_numel].view(e.rp, e.npad)
         done.add(id(mod))
     for pid, (e, role, mod) in plans.items():
         if all(hasattr(e, a) for a in ("down_w16", "up_w16")):

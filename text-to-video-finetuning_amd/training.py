@@ -121,8 +121,10 @@ class DenoiseTrainer:
     (RCCL all-reduce of the flat LoRA gradient) -> clip -> AdamW."""
 
     def __init__(self, unet, vae, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
-                 scheduler=None, process_group=None, world_size=1):
+                 scheduler=None, process_group=None, world_size=1, text_encoder=None):
         self.unet, self.vae = unet, vae
+        self.text_encoder = text_encoder           # frozen CLIPTextModel (train.py:784-790); runs through stock torch ops
+        self.batch_passes = True                   # evaluate the two UNet passes of train.py:814 as one stacked forward
         self.scheduler = scheduler or DDPMScheduler()
         self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet)
         self.pg, self.world = process_group, world_size
@@ -142,7 +144,14 @@ class DenoiseTrainer:
         else:
             timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bsz,), device=latents.device).long()
         noisy = self.scheduler.add_noise(latents, noise, timesteps)
-        ehs = batch["encoder_hidden_states"]
+        if "encoder_hidden_states" in batch:
+            ehs = batch["encoder_hidden_states"]
+        else:                                        # train.py:784-790 (frozen text encoder, no grad)
+            ids = batch["prompt_ids"]
+            if ids.dim() > 2:
+                ids = ids[0]
+            with torch.no_grad():
+                ehs = self.text_encoder(ids)[0]
         if self.scheduler.prediction_type == "epsilon":
             target = noise
         elif self.scheduler.prediction_type == "v_prediction":
@@ -150,6 +159,13 @@ class DenoiseTrainer:
         else:
             raise ValueError(f"Unknown prediction type {self.scheduler.prediction_type}")
         video_length = latents.shape[2]
+        if video_length > 1 and self.batch_passes:
+            # train.py:814-834 runs the UNet twice on the same (noisy, t, text) and sums the two MSEs (text not trainable).
+            # The two passes are independent, so they are evaluated as ONE forward over the stacked pair — the same
+            # arithmetic per pass (every statistic in the net is per sample), twice the rows per kernel launch.
+            pred = self.unet(torch.cat([noisy, noisy], 0), torch.cat([timesteps, timesteps], 0),
+                             encoder_hidden_states=torch.cat([ehs, ehs], 0)).sample
+            return mse_loss(pred[:bsz].float(), target.float()) + mse_loss(pred[bsz:].float(), target.float())
         losses = []
         for i in range(2):                            # train.py:814: two passes, losses summed
             pred = self.unet(noisy, timesteps, encoder_hidden_states=ehs).sample
@@ -162,6 +178,8 @@ class DenoiseTrainer:
         self.opt.refresh_bf16()            # bf16 copies of every LoRA factor for this step: one cast kernel
         loss = self.loss_fn(batch)
         loss.backward()
+        from .functional import join_side_stream
+        join_side_stream()                 # factor-gradient launches (side stream) complete before clip/AdamW/all-reduce
         return loss.detach()
 
     def _exchange_and_update(self):
