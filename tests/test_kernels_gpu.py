@@ -238,3 +238,15 @@ def test_lora_composition_matches_reference_golden():
         y = F.conv_linear(t, st["lora_up.weight"].cuda(), residual=y, alpha=it["scale"])
         ref = it["y"].reshape(-1, it["y"].shape[-1])
         assert relerr(y[:, : ref.shape[1]], ref) < 3e-2, name
+
+
+@pytest.mark.parametrize("M,N,r", [(300, 320, 16), (1024, 1288, 8), (77, 64, 32)])
+def test_lowrank_update(M, N, r):
+    """y += s * t @ U (the LoRA up-projection pass) against torch fp32."""
+    import t2v_amd.native as nv
+    g = torch.Generator().manual_seed(M + N + r)
+    y = _bf(torch.randn(M, N, generator=g)); t = _bf(torch.randn(M, r, generator=g)); U = _bf(torch.randn(r, N, generator=g))
+    ref = y.float() + 0.7 * (t.float() @ U.float())
+    yd, td, Ud = y.cuda(), t.cuda(), U.cuda()
+    nv.call("t2v_lowrank_update", yd.data_ptr(), N, td.data_ptr(), r, Ud.data_ptr(), N, M, N, r, 0.7, nv.stream())
+    assert relerr(yd, ref) < 1e-2

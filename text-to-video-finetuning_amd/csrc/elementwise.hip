@@ -2,6 +2,7 @@
 // layout/dtype conversion at the 4-channel latent boundary, small-channel direct convolution, MSE loss,
 // global grad-norm and fused AdamW.  16-byte accesses per lane, grid-stride loops, fp32 math.
 #include <stdarg.h>
+#include <algorithm>
 #include "common.h"
 
 // ------------------------------------------------------------------ error plumbing (thread-local, see t2v_abi.h)
@@ -27,10 +28,11 @@ inline int grid_for(long long n) { return (int)max(1LL, min((n + 255) / 256, (lo
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
                                                          long long ldy, long long rows, int inner) {
   const int cpr = inner >> 3;
-  const long long n = rows * cpr;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    long long r = i / cpr;
-    int c = (int)(i - r * cpr) * 8;
+  const unsigned n = (unsigned)(rows * cpr);            // < 2^31 (host check)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned ur = i / (unsigned)cpr;
+    const long long r = ur;
+    int c = (int)(i - ur * (unsigned)cpr) * 8;
     bf16x8 h = *(const bf16x8*)(x + r * ldx + c);
     bf16x8 g = *(const bf16x8*)(x + r * ldx + inner + c);
     bf16x8 o;
@@ -43,10 +45,11 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
                                                          const bf16_t* __restrict__ dy, long long lddy,
                                                          bf16_t* __restrict__ dx, long long lddx, long long rows, int inner) {
   const int cpr = inner >> 3;
-  const long long n = rows * cpr;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    long long r = i / cpr;
-    int c = (int)(i - r * cpr) * 8;
+  const unsigned n = (unsigned)(rows * cpr);            // < 2^31 (host check)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned ur = i / (unsigned)cpr;
+    const long long r = ur;
+    int c = (int)(i - ur * (unsigned)cpr) * 8;
     bf16x8 h = *(const bf16x8*)(x + r * ldx + c);
     bf16x8 g = *(const bf16x8*)(x + r * ldx + inner + c);
     bf16x8 d = *(const bf16x8*)(dy + r * lddy + c);
@@ -204,6 +207,57 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(const bf16_t* __restr
   }
 }
 
+// rank-r update of a token matrix: y[m, n] += scale * sum_j t[m, j] * U[j, n]   (r <= 32, bf16 in/out, fp32 math).
+// The LoRA up-projection (utils/lora.py:60-61) and the linear case of dx += dt D are exactly this; it is an
+// HBM-bound streaming pass over y, so it runs as a streaming kernel (16-byte chunks, U tile in LDS) instead of a
+// K=16 launch of the MFMA GEMM.  grid = (column blocks of 256, row blocks); block = 256 threads.
+template <int R>
+__global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict__ y, long long ldy, const bf16_t* __restrict__ t,
+                                                              long long ldt, const bf16_t* __restrict__ U, long long ldu,
+                                                              long long M, int N, float scale, int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) bf16_t sU[R * 256];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 256;
+  const int ncols = min(256, N - n0);                    // multiple of 8
+  for (int i = tid; i < R * 32; i += 256) {              // R rows x 32 chunks of 8 columns
+    int j = i >> 5, cc = i & 31;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cc * 8 < ncols) v = *(const bf16x8*)(U + (long long)j * ldu + n0 + cc * 8);
+    *(bf16x8*)(sU + j * 256 + cc * 8) = v;
+  }
+  __syncthreads();
+  const int cpr = ncols >> 3;                            // chunks per row in this column block
+  const int cc = tid % 32, rsub = tid / 32;              // 8 rows x 32 chunks per pass
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  if (cc >= cpr) return;
+  for (long long row = r0 + rsub; row < r1; row += 8) {
+    float tv[R];
+    const bf16_t* tp = t + row * ldt;
+#pragma unroll
+    for (int j8 = 0; j8 < R / 8; ++j8) {
+      bf16x8 v = *(const bf16x8*)(tp + j8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tv[j8 * 8 + e] = bf2f((unsigned short)v[e]) * scale;
+    }
+    bf16_t* yp = y + row * ldy + n0 + cc * 8;
+    bf16x8 yv = *(const bf16x8*)yp;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bf2f((unsigned short)yv[e]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      bf16x8 u = *(const bf16x8*)(sU + j * 256 + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += tv[j] * bf2f((unsigned short)u[e]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(acc[e]);
+    *(bf16x8*)yp = o;
+  }
+}
+
 // direct convolution for tiny channel counts: one thread per (output position, output channel)
 __global__ __launch_bounds__(256) void smallconv_kernel(const T2VSmallConv p) {
   const T2VConvGeom g = p.geom;
@@ -309,14 +363,36 @@ extern "C" int t2v_dropout_mask(const void* x, long long ldx, void* y, long long
   T2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "t2v_dropout_mask: bad args");
   LAUNCH1D(dropout_mask_kernel, rows * cols, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, p, seed);
 }
+extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M,
+                                  int N, int r, float scale, t2v_stream_t s) {
+  T2V_CHECK_ARG(y && t && U && M > 0 && N > 0 && N % 8 == 0 && ldy % 8 == 0 && ldt % 8 == 0 && ldu % 8 == 0,
+                "t2v_lowrank_update: bad args");
+  T2V_CHECK_ARG(r == 8 || r == 16 || r == 24 || r == 32, "t2v_lowrank_update: rank must be 8, 16, 24 or 32 (got %d)", r);
+  const int ncb = (N + 255) / 256;
+  long long want_blocks = 2048;
+  int rpb = (int)std::max<long long>(8, ((M * ncb + want_blocks - 1) / want_blocks + 7) / 8 * 8);
+  dim3 grid(ncb, (unsigned)((M + rpb - 1) / rpb));
+#define T2V_LRU(RR)                                                                                                      \
+  hipLaunchKernelGGL(lowrank_update_kernel<RR>, grid, dim3(256), 0, (hipStream_t)s, (bf16_t*)y, ldy, (const bf16_t*)t, ldt, \
+                     (const bf16_t*)U, ldu, M, N, scale, rpb)
+  if (r == 8) T2V_LRU(8);
+  else if (r == 16) T2V_LRU(16);
+  else if (r == 24) T2V_LRU(24);
+  else T2V_LRU(32);
+#undef T2V_LRU
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
 extern "C" int t2v_geglu_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int inner, t2v_stream_t s) {
   T2V_CHECK_ARG(x && y && rows > 0 && inner > 0 && inner % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_geglu_fwd: bad args");
+  T2V_CHECK_ARG((long long)rows * (inner >> 3) < (1LL << 31), "t2v_geglu_fwd: tensor too large");
   LAUNCH1D(geglu_fwd_kernel, (long long)rows * (inner >> 3), s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (long long)rows, inner);
 }
 extern "C" int t2v_geglu_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int rows,
                              int inner, t2v_stream_t s) {
   T2V_CHECK_ARG(x && dy && dx && rows > 0 && inner % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
                 "t2v_geglu_bwd: bad args");
+  T2V_CHECK_ARG((long long)rows * (inner >> 3) < (1LL << 31), "t2v_geglu_bwd: tensor too large");
   LAUNCH1D(geglu_bwd_kernel, (long long)rows * (inner >> 3), s, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx,
            lddx, (long long)rows, inner);
 }

@@ -821,30 +821,33 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   T2VGemm q = p;
   if (q.R == q.D) q.R = nullptr;       // in-place accumulation must not be applied once per timing run
   q.drop_p = 0.f;
+  const char* tl_env = getenv("T2V_GEMM_TUNE_LOG");
+  const int tune_log = tl_env ? atoi(tl_env) : 0;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
   DmaCfg best = heuristic_cfg(p);
   float best_ms = 1e30f;
   for (const DmaCfg& c : cand) {
     if (launch_dma_cfg(q, c, s) != T2V_OK) continue;      // warm (also sets the LDS attribute)
-    hipEventRecord(e0, s);
+    (void)hipEventRecord(e0, s);
     launch_dma_cfg(q, c, s);
     launch_dma_cfg(q, c, s);
-    hipEventRecord(e1, s);
+    (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess) continue;
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (tune_log > 1) fprintf(stderr, "[t2v tune]   M=%d N=%d K=%d conv=%d tile %d stages %d split %d: %.1f us\n", p.M, p.N, p.K, p.a_mode, c.tile, c.stages, c.split, ms * 500.f);
     if (ms < best_ms) { best_ms = ms; best = c; }
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   (void)hipGetLastError();
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = best;
   }
-  if (getenv("T2V_GEMM_TUNE_LOG"))
+  if (tune_log)
     fprintf(stderr, "[t2v tune] M=%d N=%d K=%d conv=%d -> tile %d stages %d split %d (%.1f us)\n", p.M, p.N, p.K, p.a_mode, best.tile,
             best.stages, best.split, best_ms * 500.f);
   return best;

@@ -143,11 +143,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   const int tpr = C >> 3, cpg = C / G;
   const float cnt = (float)rows_per_domain * cpg, icnt = 1.f / cnt;
   const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const long long nchunks = nrows * tpr;
-  for (long long ci = (long long)blockIdx.x * 256 + threadIdx.x; ci < nchunks; ci += (long long)gridDim.x * 256) {
-    const long long row = ci / tpr;
-    const int cc = (int)(ci - row * tpr);
-    const int d = (int)(row / rows_per_domain);
+  const unsigned nchunks = (unsigned)(nrows * tpr);      // < 2^31 (checked on the host): 32-bit index math, no 64-bit divides
+  for (unsigned ci = blockIdx.x * 256u + threadIdx.x; ci < nchunks; ci += gridDim.x * 256u) {
+    const unsigned urow = ci / (unsigned)tpr;
+    const int cc = (int)(ci - urow * (unsigned)tpr);
+    const int d = (int)(urow / (unsigned)rows_per_domain);
+    const long long row = urow;
     bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
     bf16x8 gv;
     if (BWD) gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
@@ -358,6 +359,7 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
   T2V_CHECK_ARG(x && y && sums && gamma && beta && ldy % 8 == 0, "t2v_gn_apply: bad args");
   long long nrows = (long long)ndomains * rows_per_domain;
   long long nchunks = nrows * (C >> 3);
+  T2V_CHECK_ARG(nchunks < (1LL << 31), "t2v_gn_apply: tensor too large for 32-bit chunk indexing");
   int grid = (int)min((nchunks + 255) / 256, (long long)8192);
   hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
                      0, (bf16_t*)y, ldy, nrows, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p,
@@ -393,6 +395,7 @@ extern "C" int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, lo
                 "t2v_gn_bwd_apply: bad args");
   long long nrows = (long long)ndomains * rows_per_domain;
   long long nchunks = nrows * (C >> 3);
+  T2V_CHECK_ARG(nchunks < (1LL << 31), "t2v_gn_bwd_apply: tensor too large for 32-bit chunk indexing");
   int grid = (int)min((nchunks + 255) / 256, (long long)8192);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nrows, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,

@@ -320,6 +320,16 @@ def join_side_stream():
     _side["refs"].clear()
 
 
+def _lowrank_update(y, t, u, M, N, r, scale):
+    """y[M,N] += scale * t[M,r] @ u[r,N] (streaming rank-r update kernel; falls back to the GEMM for ranks > 32)."""
+    if r in (8, 16, 24, 32):
+        nv.call("t2v_lowrank_update", y.data_ptr(), _ld(y), t.data_ptr(), _ld(t), u.data_ptr(), _ld(u), M, N, r, scale,
+                nv.stream())
+    else:
+        launch_gemm(M=M, N=N, K=r, A=t.data_ptr(), lda=_ld(t), B=u.data_ptr(), ldb=_ld(u), b_trans=1, D=y.data_ptr(), ldd=_ld(y),
+                    R=y.data_ptr(), ldr=_ld(y), alpha=scale)
+
+
 class _LoraLayer(torch.autograd.Function):
     """One LoRA-wrapped layer: y = base(x) + scale * up(down(x)) (utils/lora.py:57-62,134-139,211-216, dropout off /
     identity selector) with the factors living in the trainer's flat buffers (lora_bank.py):
@@ -351,8 +361,7 @@ class _LoraLayer(torch.autograd.Function):
                     rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
                     R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
                     B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
-        launch_gemm(M=M, N=npad, K=e.rp, A=t.data_ptr(), lda=e.rp, B=e.up_w16.data_ptr(), ldb=npad, b_trans=1, D=y.data_ptr(),
-                    ldd=npad, R=y.data_ptr(), ldr=npad, alpha=scale)
+        _lowrank_update(y, t, e.up_w16, M, npad, e.rp, scale)                  # y += s t U^T
         ctx.cfg, ctx.e, ctx.scale = cfg, e, scale
         ctx.has = (rowbias is not None, residual is not None)
         ctx.save_for_backward(x, t, w_base, rowbias)
@@ -381,8 +390,7 @@ class _LoraLayer(torch.autograd.Function):
             launch_gemm(M=M, N=cin_p + e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
                         D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=npad, n_split=cin_p, D2=dt.data_ptr(),
                         ldd2=e.rp)
-            launch_gemm(M=M, N=cin_p, K=e.rp, A=dt.data_ptr(), lda=e.rp, B=e.down_w16.data_ptr(), ldb=cin_p, b_trans=1,
-                        D=dx.data_ptr(), ldd=cin_p, R=dx.data_ptr(), ldr=cin_p, alpha=scale)
+            _lowrank_update(dx, dt, e.down_w16, M, cin_p, e.rp, scale)           # dx += s dt D
         else:
             launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=npad, D=dt.data_ptr(),
                         ldd=e.rp)

@@ -91,6 +91,7 @@ SYMBOLS = {
     "t2v_attn_bwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_softmax_rows": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_void_p], c_int),
     "t2v_dropout_mask": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_float, c_ull, c_void_p], c_int),
+    "t2v_lowrank_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_void_p], c_int),
     "t2v_geglu_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_geglu_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_silu_fwd": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),
