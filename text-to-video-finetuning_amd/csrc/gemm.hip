@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const T2VGemm p, int
 // pick the tile that minimises (waves of workgroups) x (tile cost); ~2 workgroups resident per CU
 // ---- NN (LDS-DMA) launch configurations: tile x ring depth x workspace split-K -------------------------------------
 struct DmaCfg {
-  int tile;    // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32, 4: 256x128 (8 waves)
+  int tile;    // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32, 4: 256x128, 5: 128x320, 6: 256x320, 7: 256x256, 8: 128x256 (4-7: 8 waves)
   int stages;  // 2 = occupancy variant, 0 = deep ring (3 for 128x128, 4 otherwise)
   int split;   // 1 = none, >1 = split K through the fp32 workspace + finalize pass
 };
@@ -725,6 +725,12 @@ int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
     case 1: rc = s2 ? launch_dma<128, 64, 2, 2, 2>(q, s) : launch_dma<128, 64, 2, 2, 4>(q, s); break;
     case 2: rc = s2 ? launch_dma<64, 64, 2, 2, 2>(q, s) : launch_dma<64, 64, 2, 2, 4>(q, s); break;
     case 4: rc = s2 ? launch_dma<256, 128, 4, 2, 2>(q, s) : launch_dma<256, 128, 4, 2, 3>(q, s); break;
+    // wide-N tiles: operand traffic per flop ~ (BM+BN)/(BM*BN); the L2->LDS DMA path (~11-12 TB/s) is what binds these
+    // kernels, so N = 320/640/1280 layers want the whole (or half the) N extent in one tile
+    case 5: rc = launch_dma<128, 320, 2, 2, 2>(q, s); break;
+    case 6: rc = launch_dma<256, 320, 4, 2, 2>(q, s); break;
+    case 7: rc = launch_dma<256, 256, 4, 2, 2>(q, s); break;
+    case 8: rc = s2 ? launch_dma<128, 256, 2, 2, 2>(q, s) : launch_dma<128, 256, 2, 2, 3>(q, s); break;
     default: rc = s2 ? launch_dma<128, 32, 4, 1, 2>(q, s) : launch_dma<128, 32, 4, 1, 4>(q, s); break;
   }
   if (rc) return rc;
@@ -802,12 +808,20 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   const int tiles_lo = p.N <= 32 ? 3 : 0, tiles_hi = p.N <= 32 ? 3 : 2;
   std::vector<int> tl;
   for (int t = tiles_lo; t <= tiles_hi; ++t) tl.push_back(t);
+  static const int BMs[9] = {128, 128, 64, 128, 256, 128, 256, 256, 128}, BNs[9] = {128, 64, 64, 32, 128, 320, 320, 256, 256};
   if (p.N > 64 && (long long)p.M * p.N >= (long long)256 * 128 * 128) tl.push_back(4);   // big outputs: 8-wave 256x128 tile
+  for (int t = 5; t <= 8; ++t) {
+    if (p.N < 256 || p.M < BMs[t]) continue;
+    long long padded = (long long)((p.N + BNs[t] - 1) / BNs[t]) * BNs[t];
+    if (padded * 100 > (long long)p.N * 115) continue;                     // <= 15 % padded columns
+    if ((long long)((p.M + BMs[t] - 1) / BMs[t]) * (padded / BNs[t]) < 96) continue;   // enough workgroups
+    tl.push_back(t);
+  }
   for (int t : tl) {
-    static const int BMs[5] = {128, 128, 64, 128, 256}, BNs[5] = {128, 64, 64, 32, 128};
     if (t < 3 && p.N <= 64 && BNs[t] > 64) continue;
     long long tiles = (long long)((p.M + BMs[t] - 1) / BMs[t]) * ((p.N + BNs[t] - 1) / BNs[t]);
     for (int st : {0, 2}) {
+      if (st == 0 && (t == 5 || t == 6 || t == 7)) continue;                 // these only exist as 2-stage rings (LDS)
       cand.push_back(DmaCfg{t, st, 1});
       if (can_split && st == 0) {
         for (int sp : {2, 4, 8, 16}) {
