@@ -158,3 +158,18 @@ def test_scheduler_matches_definition_and_zero_terminal_snr():
     b2 = S.enforce_zero_terminal_snr(S.scaled_linear_betas())
     acp2 = torch.cumprod(1 - b2, 0)
     assert acp2[-1].abs() < 1e-8 and torch.allclose(acp2[0], acp[0], atol=1e-6)      # train.py:360-389 property
+
+
+def test_fast_temporal_conv3d_is_the_same_convolution():
+    """The CPU-baseline helper (Conv3d (k,1,1) evaluated as conv2d) must not change results."""
+    from oracle.fastconv import fast_temporal_conv3d
+    from oracle.unet3d import TemporalConvLayer
+    torch.manual_seed(0)
+    tc = TemporalConvLayer(64, 64).eval()
+    torch.nn.init.normal_(tc.conv4[-1].weight, std=0.1)
+    x = torch.randn(2 * 6, 64, 5, 7)
+    y0 = tc(x, num_frames=6)
+    with fast_temporal_conv3d():
+        y1 = tc(x, num_frames=6)
+    assert torch.allclose(y0, y1, atol=1e-5, rtol=1e-5)
+    assert not hasattr(torch.nn.Conv3d, "_t2v_orig_conv_forward")
