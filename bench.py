@@ -120,13 +120,24 @@ def gemm_roofline(trainer, batch):
         nn_kernel = not kw.get("a_trans", 0) and not kw.get("b_trans", 0)
         records.append((flops, s, e, nn_kernel))
 
+    orig_pair = F.launch_gemm_pair
+
+    def timed_pair(kw_a, kw_b):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        orig_pair(kw_a, kw_b)
+        e.record()
+        records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False))
+
     F.launch_gemm = timed
+    F.launch_gemm_pair = timed_pair
     try:
         trainer.opt.zero_grad()
         trainer._fwd_bwd(batch)
         torch.cuda.synchronize()
     finally:
         F.launch_gemm = orig
+        F.launch_gemm_pair = orig_pair
     out = {}
     for name, sel in (("nn", True), ("kmajor", False)):
         rs = [r for r in records if r[3] == sel]

@@ -96,6 +96,9 @@ typedef struct {
   void* workspace; size_t workspace_bytes; int ws_split;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
+/* Two independent K-major problems (a_trans = b_trans = 1, fp32 atomic output) in ONE launch: the two LoRA factor
+ * gradients dU = s t^T dy and dD = s dt^T x_col of a wrapped layer (backward of utils/lora.py:57-62). */
+int t2v_gemm_pair(const T2VGemm* a, const T2VGemm* b, t2v_stream_t stream);
 
 /* direct small-channel conv (Cin<=8 or Cout<=8): conv_in 4->320, conv_out 320->4
  * (models/unet_3d_condition.py:132-134,249-251), VAE conv_in 3->128, conv_out 512->8, quant_conv 8->8.
@@ -113,7 +116,8 @@ int t2v_smallconv(const T2VSmallConv* p, t2v_stream_t stream);
  * (models/unet_3d_condition.py:239-243,488-490).  A "domain" = the rows one statistic spans: H*W rows
  * (per-frame norms) or F*H*W rows (5-D temporal norms).  sums: fp32 [ndomains, G, 2] = (sum, sumsq), written (not
  * accumulated).  Statistics are reduced in a fixed order (no atomics): results are bit-reproducible.
- * workspace: fp32 scratch of t2v_gn_workspace_floats(ndomains, G) elements. */
+ * workspace: fp32 scratch of t2v_gn_workspace_floats(ndomains, G) elements, ZERO-filled before its first use (it holds
+ * per-split partials and the arrival counters of the last-block reduction; the kernels leave the counters zero). */
 long long t2v_gn_workspace_floats(int ndomains, int G);
 int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows_per_domain, int C, int G,
                  float* sums, float* workspace, t2v_stream_t stream);

@@ -137,3 +137,44 @@ def test_lora_bank_layouts_are_gemm_layouts():
             else:
                 f2 = flat.view(e.rp, e.npad)
                 assert torch.equal(f2[: e.r, : e.n], p.detach().flatten(1).t()) and f2[e.r:].abs().sum() == 0
+
+
+def test_stable_lora_flavour_cpu_semantics(tmp_path):
+    """stable_lora mirror: layers re-materialise W + (B@A).view()*scaling (stable_lora/lora.py:119-126,190-197), injection
+    shares weight/bias, only lora_ params train, full-weights safetensors round trip."""
+    import torch.nn.functional as TF
+    from t2v_amd.stable_lora import lora as SL
+    from t2v_amd.utils.lora_handler import LoraHandler, LoraVersions
+    torch.manual_seed(0)
+    c = SL.Conv2d(8, 12, 3, r=4, lora_alpha=4, merge_weights=False, padding=1)
+    torch.nn.init.normal_(c.lora_B, std=0.1)
+    x = torch.randn(2, 8, 5, 5)
+    w = c.weight + (c.lora_B @ c.lora_A).view(c.weight.shape) * 1.0
+    assert torch.allclose(c(x), TF.conv2d(x, w, c.bias, padding=1), atol=1e-6)
+    c3 = SL.Conv3d(8, 8, 3, r=4, lora_alpha=4, merge_weights=False, padding=(1, 0, 0))
+    torch.nn.init.normal_(c3.lora_B, std=0.1)
+    x3 = torch.randn(1, 8, 4, 3, 3)
+    w3 = c3.weight + torch.mean((c3.lora_B @ c3.lora_A).view(8, 8, 3, 3, 1), dim=-2, keepdim=True)
+    assert torch.allclose(c3(x3), TF.conv3d(x3, w3, c3.bias, padding=(1, 0, 0)), atol=1e-6)
+    lin = SL.Linear(16, 8, r=4, lora_alpha=4, merge_weights=False)
+    torch.nn.init.normal_(lin.lora_B, std=0.1)
+    xl = torch.randn(3, 16)
+    assert torch.allclose(lin(xl), TF.linear(xl, lin.weight + lin.lora_B @ lin.lora_A, lin.bias), atol=1e-6)
+    m = _unet()
+    h = LoraHandler(version=LoraVersions.stable_lora, use_unet_lora=True)
+    params, neg = h.add_lora_to_model(True, m, ["Transformer2DModel", "ResnetBlock2D"], 0.0, None, r=4)
+    assert params is m and neg is None
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert trainable and all("lora_" in n for n in trainable)
+    n_lora = sum(1 for x_ in m.modules() if isinstance(x_, SL._LORA_TYPES))
+    assert n_lora == 271            # same layer count the reference cloneofsimo injector finds for this target list (golden)
+    h.save_lora_weights(m, str(tmp_path), step=3)
+    f = tmp_path / "full_weights" / "3_lora_text_to_video_unet.safetensors"
+    assert f.exists()
+    for x_ in m.modules():
+        if isinstance(x_, SL._LORA_TYPES):
+            torch.nn.init.normal_(x_.lora_B, std=0.02)
+    before = {k: v.clone() for k, v in SL.lora_state_dict(m).items()}
+    SL.load_lora(m, str(f))
+    after = SL.lora_state_dict(m)
+    assert any(not torch.equal(before[k], after[k]) for k in before)      # saved zeros for lora_B were restored

@@ -173,3 +173,14 @@ def test_fast_temporal_conv3d_is_the_same_convolution():
         y1 = tc(x, num_frames=6)
     assert torch.allclose(y0, y1, atol=1e-5, rtol=1e-5)
     assert not hasattr(torch.nn.Conv3d, "_t2v_orig_conv_forward")
+
+
+def test_product_zero_terminal_snr_matches_oracle_restatement():
+    from oracle import scheduler as S
+    from t2v_amd.schedulers import DDPMScheduler, enforce_zero_terminal_snr
+    b = S.scaled_linear_betas()
+    assert torch.allclose(enforce_zero_terminal_snr(b), S.enforce_zero_terminal_snr(b))
+    d = DDPMScheduler()
+    acp = d.alphas_cumprod.clone()
+    d.rescale_betas()
+    assert torch.equal(d.alphas_cumprod, acp)      # reference quirk: add_noise is unaffected (train.py:689-690)

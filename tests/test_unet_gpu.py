@@ -67,3 +67,43 @@ def test_unet_full_backward_matches_oracle():
     print('whole-gradient relerr', e, 'loss', ld.item(), lr.item())
     # reference recipe (torch.autocast bf16 on CPU vs fp32) measures 1.1e-1 on this model; native path ~1.0e-1
     assert e < 0.15
+
+
+def test_stable_lora_flavour_matches_cpu():
+    """stable_lora-style layers (`lora_A/lora_B`, W + (B@A).view()*scaling) injected into both trees: the native path
+    forms the effective weight and runs the implicit-GEMM kernels; loss and factor gradients track the CPU evaluation."""
+    from t2v_amd.stable_lora import lora as SL
+    ref, dut = _pair()
+    dut = dut.cpu()
+    kw = dict(target_module=["Transformer2DModel", "ResnetBlock2D", "TransformerTemporalModel", "TemporalConvLayer"],
+              search_class=[torch.nn.Linear, torch.nn.Conv2d, torch.nn.Conv3d], r=4)
+    SL.add_lora_to(ref, **kw)(); SL.add_lora_to(dut, **kw)()
+    g = torch.Generator().manual_seed(3)
+    for (n, p), (n2, p2) in zip(ref.named_parameters(), dut.named_parameters()):
+        assert n == n2
+        if "lora_B" in n:
+            p.data.normal_(0, 0.02, generator=g)
+        if "lora_" in n:
+            p2.data.copy_(p.data)
+    dut = dut.cuda()
+    ref.train(); dut.train()
+    for m in list(ref.modules()) + list(dut.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x, t, ehs = _inputs()
+    target = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    lr = torch.nn.functional.mse_loss(ref(x, t, ehs).sample, target); lr.backward()
+    ld = torch.nn.functional.mse_loss(dut(x.cuda(), t.cuda(), ehs.cuda()).sample, target.cuda()); ld.backward()
+    print('stable_lora loss', lr.item(), ld.item())
+    assert abs(ld.item() - lr.item()) / abs(lr.item()) < 5e-3
+    gr = dict(ref.named_parameters())
+    errs = []
+    for n, p in dut.named_parameters():
+        if "lora_" in n:
+            assert p.grad is not None, n
+            errs.append(relerr(p.grad, gr[n].grad))
+        else:
+            assert not p.requires_grad
+    errs.sort()
+    print('stable_lora factor-grad relerr median/max', errs[len(errs) // 2], errs[-1])
+    assert errs[len(errs) // 2] < 5e-2 and errs[-1] < 0.5    # same bounds as the base-weight gradients above

@@ -397,8 +397,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
-__global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem, const int bid, const int ntiles, const int z) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int LDA_T = BM + 32, LDB_T = BN + 32;  // K-major LDS row strides (elements): +64 B keeps tr reads conflict-free
   constexpr int A_BYTES = AT ? BK * LDA_T * 2 : BM * BK * 2;
@@ -413,10 +412,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
 
   // ---- XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles
   const int ntn = (N + BN - 1) / BN;
-  const int ntiles = gridDim.x;
   int t;
   {
-    int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tm = t / ntn, tn = t - tm * ntn;
@@ -426,7 +424,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
   int kbeg = 0, kend = p.K;
-  const int z = blockIdx.z;
   long long zoffD = 0, zoffR = 0;
   if (p.split_k > 1) {
     int per = ((p.K + p.split_k - 1) / p.split_k + BK - 1) / BK * BK;
@@ -636,6 +633,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
   }
 
   epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, z, zoffD, zoffR);
+}
+
+template <int BM, int BN, int WM, int WN, bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemm_body<BM, BN, WM, WN, AT, BT>(p, smem, blockIdx.x, gridDim.x, blockIdx.z);
+}
+
+// two independent problems in ONE launch (the two factor gradients dU, dD of a LoRA layer): flat grid, problem 0 owns
+// the first n0 = tiles0*z0 workgroups
+template <int BM, int BN, int WM, int WN, bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const T2VGemm p0, const T2VGemm p1, int tiles0, int z0, int tiles1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x, n0 = tiles0 * z0;
+  if (b < n0)
+    gemm_body<BM, BN, WM, WN, AT, BT>(p0, smem, b % tiles0, tiles0, b / tiles0);
+  else
+    gemm_body<BM, BN, WM, WN, AT, BT>(p1, smem, (b - n0) % tiles1, tiles1, (b - n0) / tiles1);
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
@@ -886,11 +901,36 @@ int dispatch(const T2VGemm& p, hipStream_t s) {
   return launch<64, 64, 2, 2, AT, BT>(p, s);
 }
 
+int check_gemm(const T2VGemm& p);
+
 }  // namespace
 
-extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
-  T2V_CHECK_ARG(pp != nullptr, "t2v_gemm: null descriptor");
-  const T2VGemm& p = *pp;
+// Two K-major (a_trans = b_trans = 1) problems with fp32 atomic output in one launch — the LoRA factor gradients
+// dU = s t^T dy and dD = s dt^T x_col of one layer (utils/lora.py:57-62 backward).
+extern "C" int t2v_gemm_pair(const T2VGemm* pa, const T2VGemm* pb, t2v_stream_t stream) {
+  T2V_CHECK_ARG(pa && pb, "t2v_gemm_pair: null descriptor");
+  for (const T2VGemm* q : {pa, pb}) {
+    if (int e = check_gemm(*q)) return e;
+    T2V_CHECK_ARG(q->a_trans && q->b_trans && q->out_mode == T2V_OUT_F32_ATOMIC && q->batch <= 1,
+                  "t2v_gemm_pair: both problems must be K-major with fp32 atomic output");
+  }
+  constexpr int BM = 64, BN = 64;
+  auto kern = gemm_pair_kernel<BM, BN, 2, 2, true, true>;
+  constexpr int SMEM = 2 * (BK * (BM + 32) * 2 + BK * (BN + 32) * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (SMEM > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const int t0 = ((pa->M + BM - 1) / BM) * ((pa->N + BN - 1) / BN), z0 = pa->split_k > 1 ? pa->split_k : 1;
+  const int t1 = ((pb->M + BM - 1) / BM) * ((pb->N + BN - 1) / BN), z1 = pb->split_k > 1 ? pb->split_k : 1;
+  hipLaunchKernelGGL(kern, dim3(t0 * z0 + t1 * z1), dim3(256), SMEM, (hipStream_t)stream, *pa, *pb, t0, z0, t1);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+namespace {
+int check_gemm(const T2VGemm& p) {
   T2V_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "t2v_gemm: bad dims M=%d N=%d K=%d", p.M, p.N, p.K);
   T2V_CHECK_ARG(p.A && p.B && p.D, "t2v_gemm: null operand");
   T2V_CHECK_ARG((p.a_trans && p.b_trans) || p.K % 8 == 0, "t2v_gemm: K=%d must be a multiple of 8", p.K);
@@ -928,6 +968,14 @@ extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
   if (p.b_tapflip)
     T2V_CHECK_ARG(p.b_trans && !p.b_conv && p.a_mode == T2V_A_CONV && p.K == p.geom.KH * p.geom.KW * p.geom.C,
                   "t2v_gemm: b_tapflip needs b_trans=1 and a conv gather on A");
+  return T2V_OK;
+}
+}  // namespace
+
+extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
+  T2V_CHECK_ARG(pp != nullptr, "t2v_gemm: null descriptor");
+  const T2VGemm& p = *pp;
+  if (int e = check_gemm(p)) return e;
   hipStream_t s = (hipStream_t)stream;
   static const bool env_init = [] {
     const char* e = getenv("T2V_GEMM_REGSTAGE");

@@ -18,8 +18,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int silu, float drop_p, unsigned long long drop_seed,
                                                         float* __restrict__ partial, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta) {
-  __shared__ float sval[256 * 17];   // per-thread (8 sums, 8 second sums), row stride 17 to dodge bank conflicts
+                                                        float* __restrict__ dbeta, float* __restrict__ out,
+                                                        unsigned* __restrict__ counters) {
+  __shared__ float sval[256 * 17];
+  __shared__ int s_last;   // per-thread (8 sums, 8 second sums), row stride 17 to dodge bank conflicts
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -117,18 +119,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     __syncthreads();
   }
   if (tid < 2 * G) partial[(((long long)d * gridDim.x + blockIdx.x) * G) * 2 + tid] = gacc;
-}
-
-// sums[d][g][w] = sum over splits: one wave per output, lanes = splits, fixed butterfly order (bit-reproducible)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nsplit,
-                                                           int G2, int nout) {
-  const int lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);      // output index = d * G2 + t
-  if (o >= nout) return;
-  const int d = o / G2, t = o - d * G2;
-  float v = lane < nsplit ? partial[((long long)d * nsplit + lane) * G2 + t] : 0.f;   // nsplit <= GN_MAX_SPLIT = 64
-  v = wave_sum(v);
-  if (lane == 0) sums[o] = v;
+  // ---- last-arriving block of this domain sums the per-split partials IN FIXED ORDER (bit-reproducible whichever
+  // block is last).  Hand-off per the agent-scope release/acquire recipe (guide G16): every wave drains its stores,
+  // one lane releases and takes a ticket; the last arriver acquires, then plain loads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned ticket = __hip_atomic_fetch_add(counters + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last) {
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    if (tid < 2 * G) {
+      float a = 0.f;
+      const float* pp = partial + (long long)d * gridDim.x * G * 2 + tid;
+      for (unsigned sidx = 0; sidx < gridDim.x; ++sidx) a += pp[(long long)sidx * G * 2];
+      out[(long long)d * G * 2 + tid] = a;
+    }
+    if (tid == 0) counters[d] = 0u;          // re-armed for the next call (stream order makes it visible)
+  }
 }
 
 // ------------------------------------------------------------------ GroupNorm apply (fwd) / dx (bwd)
@@ -335,7 +348,13 @@ int gn_splits(int ndomains, int rows_per_domain, int C) {
 }
 }  // namespace
 
-extern "C" long long t2v_gn_workspace_floats(int ndomains, int G) { return (long long)ndomains * GN_MAX_SPLIT * G * 2; }
+// workspace = [GN_MAX_DOMAINS] arrival counters (zero on first use; the kernels leave them zero) followed by
+// [ndomains][GN_MAX_SPLIT][G][2] partial sums.  The counters sit at a FIXED place so that partials of another call (other
+// ndomains/G) can never land on them.
+constexpr int GN_MAX_DOMAINS = 4096;
+extern "C" long long t2v_gn_workspace_floats(int ndomains, int G) {
+  return GN_MAX_DOMAINS + (long long)ndomains * GN_MAX_SPLIT * G * 2;
+}
 
 extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows_per_domain, int C, int G, float* sums,
                             float* workspace, t2v_stream_t stream) {
@@ -343,11 +362,11 @@ extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows
   T2V_CHECK_ARG(x && sums && workspace && ndomains > 0 && rows_per_domain > 0 && G <= 128, "t2v_gn_stats: bad args");
   const int ns = gn_splits(ndomains, rows_per_domain, C);
   dim3 grid(ns, ndomains);
+  T2V_CHECK_ARG(ndomains <= GN_MAX_DOMAINS, "t2v_gn_stats: more than %d domains", GN_MAX_DOMAINS);
+  unsigned* counters = (unsigned*)workspace;
   hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0,
-                     rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, workspace, nullptr, nullptr);
-  T2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((ndomains * 2 * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, sums, ns, 2 * G,
-                     ndomains * 2 * G);
+                     rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, workspace + GN_MAX_DOMAINS, nullptr,
+                     nullptr, sums, counters);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -377,11 +396,11 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_gn_bwd_stats: dgamma/dbeta must both be set or NULL");
   const int ns = gn_splits(ndomains, rows_per_domain, C);
   dim3 grid(ns, ndomains);
+  T2V_CHECK_ARG(ndomains <= GN_MAX_DOMAINS, "t2v_gn_bwd_stats: more than %d domains", GN_MAX_DOMAINS);
+  unsigned* counters = (unsigned*)workspace;
   hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, workspace, dgamma, dbeta);
-  T2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((ndomains * 2 * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, bsums, ns, 2 * G,
-                     ndomains * 2 * G);
+                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, workspace + GN_MAX_DOMAINS, dgamma,
+                     dbeta, bsums, counters);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

@@ -146,7 +146,15 @@ def _pad_vec(v, n):
 
 
 # --------------------------------------------------------------------------- raw launches
-def launch_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0, b_conv=0, geom=None, out_mode=0,
+def launch_gemm(**kw):
+    nv.call("t2v_gemm", C.byref(make_gemm(**kw)), nv.stream())
+
+
+def launch_gemm_pair(kw_a, kw_b):
+    nv.call("t2v_gemm_pair", C.byref(make_gemm(**kw_a)), C.byref(make_gemm(**kw_b)), nv.stream())
+
+
+def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0, b_conv=0, geom=None, out_mode=0,
                 bias=None, rowbias=None, ldrb=0, rows_per_rb=0, R=None, ldr=0, alpha=1.0, beta=1.0, act=0, batch=1,
                 strideA=0, strideB=0, strideD=0, strideR=0, split_k=1, drop_p=0.0, drop_seed=0, B2=None, ldb2=0, n_split=0,
                 D2=None, ldd2=0, b_tapflip=0):
@@ -168,7 +176,7 @@ def launch_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans
     if out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
         ws = _gemm_workspace()
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    nv.call("t2v_gemm", C.byref(g), nv.stream())
+    return g
 
 
 _gemm_ws = {}
@@ -413,13 +421,14 @@ class _LoraLayer(torch.autograd.Function):
         # factor gradients, accumulated in place in the flat fp32 gradient buffer (side stream: see _side above)
         kw = cfg.taps() * cin_p
 
-        def wgrads():
-            launch_gemm(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy.data_ptr(), ldb=_ld(dy), b_trans=1,
-                        D=e.up_g.data_ptr(), ldd=npad, out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
-                        split_k=_split_k((npad + 63) // 64, M))
-            launch_gemm(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
-                        b_conv=1 if conv else 0, geom=cfg.fwd_geom(cin_p) if conv else None, D=e.down_g.data_ptr(), ldd=kw,
-                        out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M))
+        def wgrads():   # dU = s t^T dy and dD = s dt^T x_col: one paired launch
+            launch_gemm_pair(
+                dict(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy.data_ptr(), ldb=_ld(dy), b_trans=1,
+                     D=e.up_g.data_ptr(), ldd=npad, out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
+                     split_k=_split_k((npad + 63) // 64, M)),
+                dict(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
+                     b_conv=1 if conv else 0, geom=cfg.fwd_geom(cin_p) if conv else None, D=e.down_g.data_ptr(), ldd=kw,
+                     out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M)))
 
         if _side["enabled"]:
             side = _side_stream()
@@ -450,7 +459,7 @@ def _gn_workspace(ndomains, G, device):
     need = int(nv.lib().t2v_gn_workspace_floats(ndomains, G))
     buf = _gn_ws.get(device)
     if buf is None or buf.numel() < need:
-        buf = _gn_ws[device] = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=device)
+        buf = _gn_ws[device] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=device)
     return buf
 
 

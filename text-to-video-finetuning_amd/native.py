@@ -74,6 +74,7 @@ SYMBOLS = {
     "t2v_abi_version": ([], c_int),
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_gemm_pair": ([C.POINTER(Gemm), C.POINTER(Gemm), c_void_p], c_int),
     "t2v_smallconv": ([C.POINTER(SmallConv), c_void_p], c_int),
     "t2v_gn_workspace_floats": ([c_int, c_int], c_ll),
     "t2v_gn_stats": ([c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),

@@ -34,3 +34,23 @@ class DDPMScheduler:
     def get_velocity(self, sample, noise, timesteps):
         a, s = self._coeffs(sample, timesteps)
         return a * noise - s * sample
+
+
+def enforce_zero_terminal_snr(betas):
+    """train.py:360-389 ("Common Diffusion Noise Schedules and Sample Steps are Flawed"): shift/scale sqrt(alpha_bar) so the
+    last timestep has zero SNR.  As in the reference (`train.py:689-690`) the result is only assigned to `.betas`; the
+    cached `alphas_cumprod` used by `add_noise` is NOT recomputed there, so `rescale_schedule` does not change training
+    noise levels — `DDPMScheduler.rescale_betas()` reproduces that behaviour."""
+    abar_sqrt = (1 - betas).cumprod(0).sqrt()
+    a0, aT = abar_sqrt[0].clone(), abar_sqrt[-1].clone()
+    abar_sqrt = (abar_sqrt - aT) * (a0 / (a0 - aT))
+    abar = abar_sqrt ** 2
+    alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+    return 1 - alphas
+
+
+def _rescale_betas(self):
+    self.betas = enforce_zero_terminal_snr(self.betas)
+
+
+DDPMScheduler.rescale_betas = _rescale_betas

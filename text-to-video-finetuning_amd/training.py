@@ -121,10 +121,16 @@ class DenoiseTrainer:
     (RCCL all-reduce of the flat LoRA gradient) -> clip -> AdamW."""
 
     def __init__(self, unet, vae, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
-                 scheduler=None, process_group=None, world_size=1, text_encoder=None):
+                 scheduler=None, process_group=None, world_size=1, text_encoder=None, use_offset_noise=False,
+                 offset_noise_strength=0.1, rescale_schedule=False):
         self.unet, self.vae = unet, vae
         self.text_encoder = text_encoder           # frozen CLIPTextModel (train.py:784-790); runs through stock torch ops
+        self._aux_stream = None
         self.batch_passes = True                   # evaluate the two UNet passes of train.py:814 as one stacked forward
+        self.use_offset_noise = use_offset_noise and not rescale_schedule      # train.py:750
+        self.offset_noise_strength = offset_noise_strength
+        if rescale_schedule:
+            self.scheduler.rescale_betas()         # train.py:689-690 (betas only; see schedulers.enforce_zero_terminal_snr)
         self.scheduler = scheduler or DDPMScheduler()
         self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet)
         self.pg, self.world = process_group, world_size
@@ -133,25 +139,32 @@ class DenoiseTrainer:
 
     # ---- train.py:720-836
     def loss_fn(self, batch):
+        ehs, aux = None, None
+        if "encoder_hidden_states" not in batch:     # train.py:784-790: frozen text encoder (no grad) — independent of the
+            ids = batch["prompt_ids"]                # VAE encode, so it runs on an auxiliary stream beside it
+            if ids.dim() > 2:
+                ids = ids[0]
+            if self._aux_stream is None:
+                self._aux_stream = torch.cuda.Stream()
+            aux = self._aux_stream
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux), torch.no_grad():
+                ehs = self.text_encoder(ids)[0]
         if "latents" in batch:                       # cache_latents path (train.py:744)
             latents = batch["latents"]
         else:
             latents = tensor_to_vae_latent(batch["pixel_values"], self.vae, batch.get("vae_eps"))
-        noise = batch["noise"] if "noise" in batch else torch.randn_like(latents)
+        noise = batch["noise"] if "noise" in batch else self.sample_noise(latents)
         bsz = latents.shape[0]
         if "timesteps" in batch:
             timesteps = batch["timesteps"]
         else:
             timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bsz,), device=latents.device).long()
         noisy = self.scheduler.add_noise(latents, noise, timesteps)
-        if "encoder_hidden_states" in batch:
+        if aux is not None:
+            torch.cuda.current_stream().wait_stream(aux)
+        else:
             ehs = batch["encoder_hidden_states"]
-        else:                                        # train.py:784-790 (frozen text encoder, no grad)
-            ids = batch["prompt_ids"]
-            if ids.dim() > 2:
-                ids = ids[0]
-            with torch.no_grad():
-                ehs = self.text_encoder(ids)[0]
         if self.scheduler.prediction_type == "epsilon":
             target = noise
         elif self.scheduler.prediction_type == "v_prediction":
@@ -173,6 +186,14 @@ class DenoiseTrainer:
             if video_length == 1 and i == 0:
                 break
         return losses[0] if len(losses) == 1 else losses[0] + losses[1]
+
+    def sample_noise(self, latents):
+        """train.py:349-358: eps ~ N(0,1), optionally plus a per-(b,c,f) offset."""
+        noise = torch.randn_like(latents)
+        if self.use_offset_noise:
+            b, c, f = latents.shape[:3]
+            noise = noise + self.offset_noise_strength * torch.randn(b, c, f, 1, 1, device=latents.device)
+        return noise
 
     def _fwd_bwd(self, batch):
         self.opt.refresh_bf16()            # bf16 copies of every LoRA factor for this step: one cast kernel
