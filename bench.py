@@ -29,6 +29,7 @@ CONFIGS = {
     "c1": (8, 128, 128, 4),       # configs[0] — the reference's CPU-runnable case
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # HBM3E peak, same guide
 
 
 def parse():
@@ -119,6 +120,10 @@ def gemm_roofline(trainer, batch):
             flops /= 4.0                                 # 3/4 of the gathered taps are structural zeros
         nn_kernel = not kw.get("a_trans", 0) and not kw.get("b_trans", 0)
         records.append((flops, s, e, nn_kernel))
+        if nn_kernel and geom is not None and geom.KH == 3 and geom.KW == 1:
+            # the (3,1,1) Conv3d launches (forward + backward-data): SURVEY 8(d) bytes = x once + y once + weights once
+            taps = 3
+            conv3d.append((flops, (kw["M"] * (kw["K"] // taps) + kw["M"] * kw["N"] + kw["N"] * kw["K"]) * 2.0, s, e))
 
     orig_pair = F.launch_gemm_pair
 
@@ -129,8 +134,33 @@ def gemm_roofline(trainer, batch):
         e.record()
         records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False))
 
+    conv3d, attn, wgrad = [], [], []
+    nv = F.nv
+    orig_call = nv.call
+
+    def timed_call(name, *a):
+        if name not in ("t2v_attn_fwd", "t2v_attn_bwd", "t2v_lora_wgrad"):
+            return orig_call(name, *a)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig_call(name, *a)
+        e.record()
+        d = a[0]._obj
+        if name == "t2v_lora_wgrad":      # each activation operand read once; fp32 factor gradients accumulated
+            taps = d.geom.KH * d.geom.KW if d.conv else 1
+            wgrad.append((2.0 * d.rp * (d.N + taps * d.C) * d.rows, (d.N + d.C) * d.rows * 2.0, s, e))
+            return r
+        bh = float(d.nbatch) * d.heads * 64
+        fwd = name == "t2v_attn_fwd"
+        flops = 4.0 * bh * d.Sq * d.Sk * (1.0 if fwd else 2.5)           # QK^T + PV; backward: 5 products
+        nbytes = bh * (2 * d.Sq + 2 * d.Sk) * 2.0 * (1.0 if fwd else 2.0)   # q,k,v,o (+ do,dq,dk,dv)
+        kind = "text_cross" if d.Sk == 77 else ("temporal" if d.Sq == d.Sk and d.Sq <= 64 else "spatial")
+        attn.append((kind, flops, nbytes, s, e))
+        return r
+
     F.launch_gemm = timed
     F.launch_gemm_pair = timed_pair
+    nv.call = timed_call
     try:
         trainer.opt.zero_grad()
         trainer._fwd_bwd(batch)
@@ -138,10 +168,31 @@ def gemm_roofline(trainer, batch):
     finally:
         F.launch_gemm = orig
         F.launch_gemm_pair = orig_pair
+        nv.call = orig_call
     out = {}
     for name, sel in (("nn", True), ("kmajor", False)):
         rs = [r for r in records if r[3] == sel]
         out[name] = dict(launches=len(rs), flops=sum(r[0] for r in rs), ms=sum(r[1].elapsed_time(r[2]) for r in rs))
+
+    def both_roofs(flops, nbytes, ms, launches):
+        t = ms * 1e-3
+        return {"launches": launches, "ms_per_step": round(ms, 3), "TFLOP/s": round(flops / t / 1e12, 1),
+                "frac_mfma_peak": round(flops / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "algorithmic_GB_per_step": round(nbytes / 1e9, 3),
+                "GB/s": round(nbytes / t / 1e9, 1), "frac_hbm_peak": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4)}
+
+    ns = {}
+    if conv3d:
+        ns["conv3d_3x1x1"] = both_roofs(sum(c[0] for c in conv3d), sum(c[1] for c in conv3d),
+                                        sum(c[2].elapsed_time(c[3]) for c in conv3d), len(conv3d))
+    if wgrad:
+        ns["lora_factor_gradients"] = both_roofs(sum(c[0] for c in wgrad), sum(c[1] for c in wgrad),
+                                                 sum(c[2].elapsed_time(c[3]) for c in wgrad), len(wgrad))
+    for kind in ("temporal", "spatial", "text_cross"):
+        rs = [r for r in attn if r[0] == kind]
+        if rs:
+            ns[f"{kind}_attention_core"] = both_roofs(sum(r[1] for r in rs), sum(r[2] for r in rs),
+                                                      sum(r[3].elapsed_time(r[4]) for r in rs), len(rs))
+    out["north_star"] = ns
     return out
 
 
@@ -275,9 +326,11 @@ def main():
                     achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     launches=rr["launches"], algorithmic_gflop_per_step=round(rr["flops"] / 1e9, 1),
                     kernel_ms_per_step=round(rr["ms"], 2), traffic=pmc_traffic(),
-                    secondary={"kernel": "gemm_kernel<..,AT=1,BT=1> - LoRA factor gradients (K-major operands, HBM-bound, side stream)",
+                    secondary={"kernel": "gemm_kernel<..,AT|BT> - K-major / transposed-operand launches (factor gradients of strided convs, "
+                                         "VAE attention P.V); the LoRA factor gradients proper are north_star_kernels.lora_factor_gradients",
                                "launches": km["launches"], "algorithmic_gflop_per_step": round(km["flops"] / 1e9, 1),
-                               "kernel_ms_per_step": round(km["ms"], 2)})
+                               "kernel_ms_per_step": round(km["ms"], 2)},
+                    north_star_kernels=both["north_star"])
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_steps)

@@ -172,6 +172,32 @@ int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long 
 int t2v_lowrank_update(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M, int N,
                        int r, float scale, t2v_stream_t stream);
 
+/* ---- LoRA factor gradients of one layer in one streaming launch (the weight-gradient half of
+ * LoraInjectedLinear/Conv2d/Conv3d, utils/lora.py:57-62,134-139,211-216, as autograd derives it):
+ *   dU[j, n]      += alpha * sum_m t[m, j]  * dy[m, n]                       (up factor, 1x1)
+ *   dD[j, tap, c] += alpha * sum_q dt[p(q, tap), j] * x[q, c]               (down factor, same window as the base layer)
+ * where p(q, tap) is the output position that reads input position q under `tap` (zero when it falls outside the image).
+ * Both are K-major contractions over the rows; the activation operands (dy, x) are streamed ONCE — the window is applied
+ * to the rank-wide operand dt instead of the 9x-replicated input gather a weight-gradient GEMM would do.
+ * fp32 outputs are accumulated with atomics (like T2V_OUT_F32_ATOMIC).  Restrictions: rank padded to a multiple of 8
+ * (<= 32); a conv geometry must be stride 1, same-size (Hv==Ho, Wv==Wo), tdiv==1, up==0, KH*KW in {1,3,9}. */
+typedef struct T2VLoraWgrad {
+  long long rows;                 /* activation rows (positions) */
+  int rp;                         /* padded rank: 8, 16, 24 or 32 */
+  int conv;                       /* 0: linear; 1: window geometry in `geom` */
+  const void* t;   long long ldt;    /* bf16 [rows, rp]  saved down-projection */
+  const void* dy;  long long lddy;   /* bf16 [rows, N] */
+  int N;
+  float* dU;       long long lddu;   /* fp32 [rp, lddu] */
+  const void* dt;  long long lddt;   /* bf16 [rows, rp]  gradient of the down-projection output */
+  const void* x;   long long ldx;    /* bf16 [rows, C]   layer input */
+  int C;
+  float* dD;       long long lddd;   /* fp32 [rp, lddd], column = tap*C + c */
+  T2VConvGeom geom;
+  float alpha;
+} T2VLoraWgrad;
+int t2v_lora_wgrad(const T2VLoraWgrad* p, t2v_stream_t stream);
+
 /* ---- elementwise ---- */
 /* GEGLU gate: y[m, j] = x[m, j] * gelu_erf(x[m, inner + j])  (FeedForward/GEGLU) */
 int t2v_geglu_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int inner, t2v_stream_t stream);

@@ -250,3 +250,51 @@ def test_lowrank_update(M, N, r):
     yd, td, Ud = y.cuda(), t.cuda(), U.cuda()
     nv.call("t2v_lowrank_update", yd.data_ptr(), N, td.data_ptr(), r, Ud.data_ptr(), N, M, N, r, 0.7, nv.stream())
     assert relerr(yd, ref) < 1e-2
+
+
+@pytest.mark.parametrize("nimg,H,W,KH,KW,C,N,rp", [
+    (1, 1, 1, 1, 1, 320, 320, 16),        # linear (rows set below), C and N multiples of 64
+    (1, 1, 1, 1, 1, 72, 1288, 8),         # linear, ragged column tiles, rank 8
+    (3, 8, 8, 3, 3, 64, 128, 16),         # conv 3x3 pad 1
+    (2, 5, 7, 3, 3, 24, 40, 32),          # conv 3x3, odd image, two rank passes
+    (2, 4, 48, 3, 1, 128, 128, 16),       # (3,1,1) Conv3d as a 3x1 window over (B, F, H*W)
+    (1, 16, 16, 3, 3, 8, 320, 24),        # conv_in-like (Cin padded to 8), ranks 16 + 8
+])
+def test_lora_wgrad(nimg, H, W, KH, KW, C, N, rp):
+    """t2v_lora_wgrad: dU = a t^T dy and dD[j,tap,c] = a sum dt[p(q,tap), j] x[q, c] against torch fp32 (autograd's
+    weight gradients of lora_up / lora_down, utils/lora.py:57-62,134-139,211-216).  Outputs accumulate (+=)."""
+    import ctypes as C_
+    import t2v_amd.native as nv
+    conv = KH * KW > 1
+    rows = nimg * H * W if conv else 1000
+    g = torch.Generator().manual_seed(rows + C + N + rp)
+    t = _bf(torch.randn(rows, rp, generator=g)); dy = _bf(torch.randn(rows, N, generator=g))
+    dt = _bf(torch.randn(rows, rp, generator=g)); x = _bf(torch.randn(rows, C, generator=g))
+    taps = KH * KW
+    dU0 = torch.randn(rp, N, generator=g); dD0 = torch.randn(rp, taps * C, generator=g)
+    a = 0.5
+    refU = dU0 + a * (t.float().T @ dy.float())
+    if conv:
+        py, px = KH // 2, KW // 2
+        xi = x.float().view(nimg, H, W, C)
+        xp = torch.zeros(nimg, H + KH - 1, W + KW - 1, C); xp[:, py:py + H, px:px + W] = xi
+        di = dt.float().view(nimg, H, W, rp)
+        parts = [torch.einsum('nhwj,nhwc->jc', di, xp[:, ky:ky + H, kx:kx + W]) for ky in range(KH) for kx in range(KW)]
+        refD = dD0 + a * torch.stack(parts, 1).reshape(rp, taps * C)
+    else:
+        refD = dD0 + a * (dt.float().T @ x.float())
+    td, dyd, dtd, xd, dU, dD = t.cuda(), dy.cuda(), dt.cuda(), x.cuda(), dU0.cuda(), dD0.cuda()
+    w = nv.LoraWgrad()
+    w.rows, w.rp, w.conv = rows, rp, int(conv)
+    w.t, w.ldt, w.dy, w.lddy, w.N = td.data_ptr(), rp, dyd.data_ptr(), N, N
+    w.dU, w.lddu = dU.data_ptr(), N
+    w.dt, w.lddt, w.x, w.ldx, w.C = dtd.data_ptr(), rp, xd.data_ptr(), C, C
+    w.dD, w.lddd = dD.data_ptr(), taps * C
+    if conv:
+        w.geom = nv.ConvGeom(C, H, W, H, W, KH, KW, 1, 1, KH // 2, KW // 2, 1, 0)
+    w.alpha = a
+    nv.call("t2v_lora_wgrad", C_.byref(w), nv.stream())
+    torch.cuda.synchronize()
+    eu, ed = relerr(dU, refU), relerr(dD, refD)
+    print('lora_wgrad relerr', eu, ed)
+    assert eu < 1e-3 and ed < 1e-3        # fp32 accumulation of exact bf16 products: only summation order differs

@@ -1,0 +1,208 @@
+// LoRA factor gradients of one layer in one streaming launch (t2v_lora_wgrad, include/t2v_abi.h).
+//
+// Both gradients are K-major contractions over the activation rows with a rank-wide (<=16 per pass) left operand:
+//   out[16, taps, C] += alpha * sum_rows S[src(row, tap), 0:16]^T * Big[row, 0:C]
+// (dU: S = t, Big = dy, taps = 1;  dD: S = dt, Big = x, taps = KH*KW).  The window of a conv is applied to the narrow
+// operand S, so the wide operand is read exactly once: HBM-bound on `Big`, MFMA work = the algorithmic 2*16*taps*C*rows.
+//
+// Workgroup = 4 wave64; tile = 64 rows x 64 columns of Big per step, wave w owns columns [16w, 16w+16) for every tap.
+// v_mfma_f32_16x16x32_bf16: A = S^T (16 x 32 rows), B = Big (32 rows x 16 cols).  Both operands are K-major in memory,
+// so both go through LDS and ds_read_tr16_b64; the contraction index is permuted (lane group g, element j <-> row
+// 16*(j>>2) + 4g + (j&3)) so that one transposed read touches 16 consecutive staged rows (conflict-free with the
+// 160-byte row pitch).  Next step's global loads are issued into registers before the current step's MFMAs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int KR = 64;      // rows staged per step (two k=32 MFMA blocks)
+constexpr int PITCH = 160;  // bytes per staged row of the wide tile: 128 data + 32 pad
+constexpr int SP = 32;      // bytes per staged row of a narrow tile (16 bf16)
+
+struct Prob {
+  const bf16_t* big;
+  long long ldbig;
+  int C;
+  const bf16_t* s;
+  long long lds;
+  float* out;
+  long long ldo;
+  int tiles;
+};
+
+struct Args {
+  Prob u, d;
+  long long rows;
+  int chunk_rows;
+  int rk;  // valid rank columns in this pass (8 or 16)
+  int conv;
+  T2VConvGeom g;
+  float alpha;
+};
+
+template <int TAPS>
+__device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, long long r_end, int c0, const T2VConvGeom& g,
+                                           int rk, float alpha, unsigned char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned char* sBig = smem;
+  unsigned char* sS = smem + KR * PITCH;
+  constexpr int NS = (TAPS * 128 + 255) / 256;
+  f32x4 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 rb[2], rs[NS];
+  const int srow = (tid & 127) >> 1, shalf = tid & 1, stap0 = tid >> 7;
+  const unsigned hw = (unsigned)(g.Hv * g.Wv);
+
+  auto fetch = [&](long long row0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, cc = id & 7;
+      const long long gr = row0 + row;
+      const int col = c0 + cc * 8;
+      rb[i] = (gr < r_end && col < P.C) ? *(const bf16x8*)(P.big + gr * P.ldbig + col) : zero8;
+    }
+    const long long q = row0 + srow;
+    const bool okq = q < r_end && shalf * 8 < rk;
+    int n = 0, iy = 0, ix = 0;
+    if (TAPS > 1) {
+      const unsigned uq = (unsigned)q;
+      n = (int)(uq / hw);
+      const unsigned rem = uq - (unsigned)n * hw;
+      iy = (int)(rem / (unsigned)g.Wv);
+      ix = (int)(rem - (unsigned)iy * (unsigned)g.Wv);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int tap = stap0 + 2 * i;
+      if (tap < TAPS) {
+        long long src = q;
+        bool v = okq;
+        if (TAPS > 1) {
+          const int ky = tap / g.KW, kx = tap - ky * g.KW;
+          const int oy = iy - ky + g.py, ox = ix - kx + g.px;
+          v = v && (unsigned)oy < (unsigned)g.Ho && (unsigned)ox < (unsigned)g.Wo;
+          src = ((long long)n * g.Ho + oy) * g.Wo + ox;
+        }
+        rs[i] = v ? *(const bf16x8*)(P.s + src * P.lds + shalf * 8) : zero8;
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, cc = id & 7;
+      *(bf16x8*)(sBig + row * PITCH + cc * 16) = rb[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int tap = stap0 + 2 * i;
+      if (tap < TAPS) *(bf16x8*)(sS + (tap * KR + srow) * SP + shalf * 16) = rs[i];
+    }
+  };
+  const int gq = lane >> 4, li = lane & 15, jq = li >> 2, q4 = li & 3;
+  auto compute = [&]() {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int rbase = 32 * h2 + 4 * gq + jq;
+      const unsigned char* pb = sBig + rbase * PITCH + w * 32 + q4 * 8;
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)pb);
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(pb + 16 * PITCH));
+      const bf16x8 b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const unsigned char* pa = sS + (t * KR + rbase) * SP + q4 * 8;
+        bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)pa);
+        bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(pa + 16 * SP));
+        const bf16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  fetch(r_begin);
+  for (long long row0 = r_begin; row0 < r_end; row0 += KR) {
+    __syncthreads();
+    stash();
+    __syncthreads();
+    if (row0 + KR < r_end) fetch(row0 + KR);
+    compute();
+  }
+  const int col = c0 + 16 * w + li;
+  if (col < P.C) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 4 * gq + r;
+        if (j < rk) atomicAdd(P.out + (long long)j * P.ldo + (long long)t * P.C + col, alpha * acc[t][r]);
+      }
+  }
+}
+
+template <int TAPS_D>
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KR * PITCH + TAPS_D * KR * SP];
+  const int ntiles = a.u.tiles + a.d.tiles;
+  const int tile = blockIdx.x % ntiles, chunk = blockIdx.x / ntiles;
+  const long long r_begin = (long long)chunk * a.chunk_rows;
+  const long long r_end = std::min(a.rows, r_begin + a.chunk_rows);
+  if (r_begin >= r_end) return;
+  if (tile < a.u.tiles)
+    wgrad_body<1>(a.u, r_begin, r_end, tile * 64, a.g, a.rk, a.alpha, smem);
+  else
+    wgrad_body<TAPS_D>(a.d, r_begin, r_end, (tile - a.u.tiles) * 64, a.g, a.rk, a.alpha, smem);
+}
+
+}  // namespace
+
+extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
+  T2V_CHECK_ARG(pp, "t2v_lora_wgrad: null descriptor");
+  const T2VLoraWgrad& p = *pp;
+  T2V_CHECK_ARG(p.rows > 0 && p.rows < (1LL << 31) && p.t && p.dy && p.dU && p.dt && p.x && p.dD, "t2v_lora_wgrad: bad args");
+  T2V_CHECK_ARG(p.rp >= 8 && p.rp <= 32 && p.rp % 8 == 0, "t2v_lora_wgrad: padded rank must be 8, 16, 24 or 32 (got %d)", p.rp);
+  T2V_CHECK_ARG(p.N > 0 && p.N % 8 == 0 && p.C > 0 && p.C % 8 == 0 && p.ldt % 8 == 0 && p.lddt % 8 == 0 && p.lddy % 8 == 0 &&
+                    p.ldx % 8 == 0,
+                "t2v_lora_wgrad: N, C and the bf16 leading dimensions must be multiples of 8 (N=%d C=%d)", p.N, p.C);
+  int taps = 1;
+  T2VConvGeom g = p.geom;
+  if (p.conv) {
+    taps = g.KH * g.KW;
+    T2V_CHECK_ARG(taps == 1 || taps == 3 || taps == 9, "t2v_lora_wgrad: window of %d taps not supported", taps);
+    T2V_CHECK_ARG(g.sy == 1 && g.sx == 1 && g.tdiv == 1 && g.up == 0 && g.Hv == g.Ho && g.Wv == g.Wo && g.Hv > 0 && g.Wv > 0,
+                  "t2v_lora_wgrad: only stride-1 same-size windows (use the K-major GEMM for the others)");
+    T2V_CHECK_ARG(p.rows % ((long long)g.Hv * g.Wv) == 0, "t2v_lora_wgrad: rows is not a whole number of %dx%d images", g.Hv, g.Wv);
+  } else {
+    g = T2VConvGeom{};
+    g.Hv = g.Wv = g.Ho = g.Wo = g.KH = g.KW = 1;
+  }
+  T2V_CHECK_ARG(p.lddu >= p.N && p.lddd >= (long long)taps * p.C, "t2v_lora_wgrad: output leading dimensions too small");
+  for (int r0 = 0; r0 < p.rp; r0 += 16) {     // one pass per 16 rank rows
+    Args a;
+    a.rk = std::min(16, p.rp - r0);
+    a.u = Prob{(const bf16_t*)p.dy, p.lddy, p.N, (const bf16_t*)p.t + r0, p.ldt, p.dU + (long long)r0 * p.lddu, p.lddu, (p.N + 63) / 64};
+    a.d = Prob{(const bf16_t*)p.x, p.ldx, p.C, (const bf16_t*)p.dt + r0, p.lddt, p.dD + (long long)r0 * p.lddd, p.lddd, (p.C + 63) / 64};
+    a.rows = p.rows;
+    a.conv = p.conv;
+    a.g = g;
+    a.alpha = p.alpha;
+    const int ntiles = a.u.tiles + a.d.tiles;
+    long long nsteps = (p.rows + KR - 1) / KR;
+    long long nchunks = std::max<long long>(1, std::min<long long>(nsteps, (384 + ntiles - 1) / ntiles));
+    a.chunk_rows = (int)(((nsteps + nchunks - 1) / nchunks) * KR);
+    nchunks = (p.rows + a.chunk_rows - 1) / a.chunk_rows;
+    dim3 grid((unsigned)(nchunks * ntiles));
+    if (taps == 1)
+      hipLaunchKernelGGL(lora_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (taps == 3)
+      hipLaunchKernelGGL(lora_wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(lora_wgrad_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    T2V_CHECK_LAUNCH();
+  }
+  return T2V_OK;
+}

@@ -421,13 +421,27 @@ class _LoraLayer(torch.autograd.Function):
         # factor gradients, accumulated in place in the flat fp32 gradient buffer (side stream: see _side above)
         kw = cfg.taps() * cin_p
 
-        def wgrads():   # dU = s t^T dy and dD = s dt^T x_col: one paired launch
-            launch_gemm_pair(
+        def wgrads():   # dU = s t^T dy and dD = s dt^T x_col, accumulated into the flat fp32 gradient buffer
+            g = cfg.fwd_geom(cin_p) if conv else None
+            if e.rp <= 32 and x.shape[0] == M and (not conv or _wgrad_window_ok(g, M)):
+                # streaming kernel: dy and x are read once, the window is applied to the rank-wide operand dt
+                w = nv.LoraWgrad()
+                w.rows, w.rp, w.conv = M, e.rp, 1 if conv else 0
+                w.t, w.ldt, w.dy, w.lddy, w.N = t.data_ptr(), _ld(t), dy.data_ptr(), _ld(dy), npad
+                w.dU, w.lddu = e.up_g.data_ptr(), npad
+                w.dt, w.lddt, w.x, w.ldx, w.C = dt.data_ptr(), _ld(dt), x.data_ptr(), _ld(x), cin_p
+                w.dD, w.lddd = e.down_g.data_ptr(), kw
+                if conv:
+                    w.geom = g
+                w.alpha = scale
+                nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+                return
+            launch_gemm_pair(     # strided / resampled windows: two K-major GEMMs in one launch
                 dict(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy.data_ptr(), ldb=_ld(dy), b_trans=1,
                      D=e.up_g.data_ptr(), ldd=npad, out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
                      split_k=_split_k((npad + 63) // 64, M)),
                 dict(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
-                     b_conv=1 if conv else 0, geom=cfg.fwd_geom(cin_p) if conv else None, D=e.down_g.data_ptr(), ldd=kw,
+                     b_conv=1 if conv else 0, geom=g, D=e.down_g.data_ptr(), ldd=kw,
                      out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M)))
 
         if _side["enabled"]:
@@ -439,6 +453,13 @@ class _LoraLayer(torch.autograd.Function):
         else:
             wgrads()
         return dx, None, None, None, None, drb, dres, None, None, None
+
+
+def _wgrad_window_ok(g, rows):
+    """t2v_lora_wgrad handles stride-1 same-size windows of 1, 3 or 9 taps (everything but the 3 stride-2 downsamplers and
+    the 3 nearest-upsampled convs of the UNet)."""
+    return (g.sy == 1 and g.sx == 1 and g.tdiv == 1 and g.up == 0 and g.Hv == g.Ho and g.Wv == g.Wo
+            and g.KH * g.KW in (1, 3, 9) and rows % (g.Hv * g.Wv) == 0)
 
 
 def lora_layer(x, w_base, b_base, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None):

@@ -21,6 +21,16 @@ class ConvGeom(C.Structure):
     _fields_ = [(n, c_int) for n in "C Hv Wv Ho Wo KH KW sy sx py px tdiv up".split()]
 
 
+class LoraWgrad(C.Structure):
+    _fields_ = [
+        ("rows", c_ll), ("rp", c_int), ("conv", c_int),
+        ("t", c_void_p), ("ldt", c_ll), ("dy", c_void_p), ("lddy", c_ll), ("N", c_int),
+        ("dU", c_void_p), ("lddu", c_ll), ("dt", c_void_p), ("lddt", c_ll),
+        ("x", c_void_p), ("ldx", c_ll), ("C", c_int), ("dD", c_void_p), ("lddd", c_ll),
+        ("geom", ConvGeom), ("alpha", c_float),
+    ]
+
+
 class Gemm(C.Structure):
     _fields_ = [
         ("M", c_int), ("N", c_int), ("K", c_int),
@@ -93,6 +103,7 @@ SYMBOLS = {
     "t2v_softmax_rows": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_void_p], c_int),
     "t2v_dropout_mask": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_lowrank_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_void_p], c_int),
+    "t2v_lora_wgrad": ([C.POINTER(LoraWgrad), c_void_p], c_int),
     "t2v_geglu_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_geglu_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_silu_fwd": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),
