@@ -120,6 +120,8 @@ def gemm_roofline(trainer, batch):
             flops /= 4.0                                 # 3/4 of the gathered taps are structural zeros
         nn_kernel = not kw.get("a_trans", 0) and not kw.get("b_trans", 0)
         records.append((flops, s, e, nn_kernel))
+        shapes.append(((kw["M"], kw["N"], kw["K"], z, "conv" if geom is not None else "lin",
+                        "nn" if nn_kernel else "tn"), flops, s, e))
         if nn_kernel and geom is not None and geom.KH == 3 and geom.KW == 1:
             # the (3,1,1) Conv3d launches (forward + backward-data): SURVEY 8(d) bytes = x once + y once + weights once
             taps = 3
@@ -134,7 +136,7 @@ def gemm_roofline(trainer, batch):
         e.record()
         records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False))
 
-    conv3d, attn, wgrad = [], [], []
+    conv3d, attn, wgrad, shapes = [], [], [], []
     nv = F.nv
     orig_call = nv.call
 
@@ -193,6 +195,14 @@ def gemm_roofline(trainer, batch):
             ns[f"{kind}_attention_core"] = both_roofs(sum(r[1] for r in rs), sum(r[2] for r in rs),
                                                       sum(r[3].elapsed_time(r[4]) for r in rs), len(rs))
     out["north_star"] = ns
+    if os.environ.get("T2V_BENCH_SHAPE_TABLE"):      # per-problem-signature GEMM time of one step (diagnostic)
+        agg = {}
+        for key, fl, s, e in shapes:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += s.elapsed_time(e); a[2] += fl
+        with open(os.environ["T2V_BENCH_SHAPE_TABLE"], "w") as f:
+            for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{str(key):60s} launches {n:4d}  ms {ms:8.3f}  us/launch {ms / n * 1e3:8.1f}  TF/s {fl / ms / 1e9:7.1f}\n")
     return out
 
 

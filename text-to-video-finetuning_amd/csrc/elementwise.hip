@@ -209,52 +209,71 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(const bf16_t* __restr
 
 // rank-r update of a token matrix: y[m, n] += scale * sum_j t[m, j] * U[j, n]   (r <= 32, bf16 in/out, fp32 math).
 // The LoRA up-projection (utils/lora.py:60-61) and the linear case of dx += dt D are exactly this; it is an
-// HBM-bound streaming pass over y, so it runs as a streaming kernel (16-byte chunks, U tile in LDS) instead of a
-// K=16 launch of the MFMA GEMM.  grid = (column blocks of 256, row blocks); block = 256 threads.
+// HBM-bound streaming pass over y, so it runs as a streaming kernel (rank-wide MFMA per 16 rows) instead of a
+// K=16 launch of the MFMA GEMM.  grid = (column blocks of 128, row blocks); block = 4 waves x 32 columns.
+// One wave owns a 32-column strip and walks rows 16 at a time: y^T tile = U^T t^T on v_mfma_f32_16x16x16_bf16 (K = 16
+// is the rank).  The strip's columns are assigned to the two MFMAs' M index so that the accumulator layout hands every
+// lane 8 CONSECUTIVE columns of one row (MFMA m, M index i <-> column 8*(i>>2) + 4*m + (i&3)): y is updated with one
+// 16-byte load and one 16-byte store per lane, t is an 8-byte load, and the VALU only converts and adds.
 template <int R>
 __global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict__ y, long long ldy, const bf16_t* __restrict__ t,
                                                               long long ldt, const bf16_t* __restrict__ U, long long ldu,
                                                               long long M, int N, float scale, int rows_per_block) {
-  __shared__ __attribute__((aligned(16))) bf16_t sU[R * 256];
-  const int tid = threadIdx.x;
-  const int n0 = blockIdx.x * 256;
-  const int ncols = min(256, N - n0);                    // multiple of 8
-  for (int i = tid; i < R * 32; i += 256) {              // R rows x 32 chunks of 8 columns
-    int j = i >> 5, cc = i & 31;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (cc * 8 < ncols) v = *(const bf16x8*)(U + (long long)j * ldu + n0 + cc * 8);
-    *(bf16x8*)(sU + j * 256 + cc * 8) = v;
-  }
-  __syncthreads();
-  const int cpr = ncols >> 3;                            // chunks per row in this column block
-  const int cc = tid % 32, rsub = tid / 32;              // 8 rows x 32 chunks per pass
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 4 + w) * 32;
+  if (c0 >= N) return;
+  const int li = lane & 15, g = lane >> 4;
+  constexpr int KS = (R + 15) / 16;
+  constexpr int UN = 4;
+  bf16x4 a[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 16 * ks + 4 * g + j, col = c0 + 8 * (li >> 2) + 4 * m + (li & 3);
+        a[ks][m][j] = (k < R && col < N) ? (short)U[(long long)k * ldu + col] : (short)0;
+      }
+  const int ccol = c0 + 8 * g;
+  const bool cok = ccol < N;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   const long long r1 = min(M, r0 + rows_per_block);
-  if (cc >= cpr) return;
-  for (long long row = r0 + rsub; row < r1; row += 8) {
-    float tv[R];
-    const bf16_t* tp = t + row * ldt;
+  const bf16x4 zero4 = {0, 0, 0, 0};
+  for (long long row0 = r0; row0 < r1; row0 += 16 * UN) {
+    bf16x8 yv[UN];
+    bf16x4 tb[UN][KS];
 #pragma unroll
-    for (int j8 = 0; j8 < R / 8; ++j8) {
-      bf16x8 v = *(const bf16x8*)(tp + j8 * 8);
+    for (int u = 0; u < UN; ++u) {
+      const long long row = row0 + 16 * u + li;
+      const bool ok = row < r1;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) tv[j8 * 8 + e] = bf2f((unsigned short)v[e]) * scale;
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = 16 * ks + 4 * g;
+        tb[u][ks] = (ok && k0 < R) ? *(const bf16x4*)(t + row * ldt + k0) : zero4;
+      }
+      if (ok && cok) yv[u] = *(const bf16x8*)(y + row * ldy + ccol);
     }
-    bf16_t* yp = y + row * ldy + n0 + cc * 8;
-    bf16x8 yv = *(const bf16x8*)yp;
-    float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bf2f((unsigned short)yv[e]);
+    for (int u = 0; u < UN; ++u) {
+      const long long row = row0 + 16 * u + li;
+      if (row0 + 16 * u >= r1) break;                      // wave-uniform
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-      bf16x8 u = *(const bf16x8*)(sU + j * 256 + cc * 8);
+      for (int ks = 0; ks < KS; ++ks) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[ks][0], tb[u][ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[ks][1], tb[u][ks], acc1, 0, 0, 0);
+      }
+      if (row < r1 && cok) {
+        bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += tv[j] * bf2f((unsigned short)u[e]);
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (short)f2bf(bf2f((unsigned short)yv[u][e]) + scale * acc0[e]);
+          o[4 + e] = (short)f2bf(bf2f((unsigned short)yv[u][4 + e]) + scale * acc1[e]);
+        }
+        *(bf16x8*)(y + row * ldy + ccol) = o;
+      }
     }
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(acc[e]);
-    *(bf16x8*)yp = o;
   }
 }
 
@@ -368,9 +387,9 @@ extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long lo
   T2V_CHECK_ARG(y && t && U && M > 0 && N > 0 && N % 8 == 0 && ldy % 8 == 0 && ldt % 8 == 0 && ldu % 8 == 0,
                 "t2v_lowrank_update: bad args");
   T2V_CHECK_ARG(r == 8 || r == 16 || r == 24 || r == 32, "t2v_lowrank_update: rank must be 8, 16, 24 or 32 (got %d)", r);
-  const int ncb = (N + 255) / 256;
+  const int ncb = (N + 127) / 128;
   long long want_blocks = 2048;
-  int rpb = (int)std::max<long long>(8, ((M * ncb + want_blocks - 1) / want_blocks + 7) / 8 * 8);
+  int rpb = (int)std::max<long long>(64, ((M * ncb + want_blocks - 1) / want_blocks + 63) / 64 * 64);
   dim3 grid(ncb, (unsigned)((M + rpb - 1) / rpb));
 #define T2V_LRU(RR)                                                                                                      \
   hipLaunchKernelGGL(lowrank_update_kernel<RR>, grid, dim3(256), 0, (hipStream_t)s, (bf16_t*)y, ldy, (const bf16_t*)t, ldt, \

@@ -63,33 +63,49 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
       }
-      for (int r = rbeg + rl; r < rend; r += rpp) {
-        const long long row = (long long)d * rows_per_domain + r;
-        bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
-        if (!BWD) {
+      constexpr int UN = 4;                 // independent 16-byte loads in flight per operand
+      for (int r0 = rbeg + rl; r0 < rend; r0 += UN * rpp) {
+        bf16x8 xq[UN], gq[UN];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = bf2f((unsigned short)xv[e]);
-            s0[e] += v;
-            s1[e] += v * v;
+        for (int u = 0; u < UN; ++u) {
+          const int rr = r0 + u * rpp;
+          if (rr < rend) {
+            const long long row = (long long)d * rows_per_domain + rr;
+            xq[u] = *(const bf16x8*)(x + row * ldx + cc * 8);
+            if (BWD) gq[u] = *(const bf16x8*)(dy + row * lddy + cc * 8);
           }
-        } else {
-          bf16x8 gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
+        }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
-            float dz = bf2f((unsigned short)gv[e]);
-            if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
-            if (silu) {
-              float zz = xh * gm[e] + bt[e];
-              float sg = sigmoid_f(zz);
-              dz *= sg * (1.f + zz * (1.f - sg));
+        for (int u = 0; u < UN; ++u) {
+          const int rr = r0 + u * rpp;
+          if (rr >= rend) continue;
+          const long long row = (long long)d * rows_per_domain + rr;
+          const bf16x8 xv = xq[u];
+          if (!BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = bf2f((unsigned short)xv[e]);
+              s0[e] += v;
+              s1[e] += v * v;
             }
-            s0[e] += dz * gm[e];           // sum dxh
-            s1[e] += dz * gm[e] * xh;      // sum dxh * xh
-            if (dgamma) {
-              a0[e] += dz * xh;
-              a1[e] += dz;
+          } else {
+            const bf16x8 gv = gq[u];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
+              float dz = bf2f((unsigned short)gv[e]);
+              if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
+              if (silu) {
+                float zz = xh * gm[e] + bt[e];
+                float sg = sigmoid_f(zz);
+                dz *= sg * (1.f + zz * (1.f - sg));
+              }
+              s0[e] += dz * gm[e];           // sum dxh
+              s1[e] += dz * gm[e] * xh;      // sum dxh * xh
+              if (dgamma) {
+                a0[e] += dz * xh;
+                a1[e] += dz;
+              }
             }
           }
         }
@@ -118,26 +134,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     }
     __syncthreads();
   }
-  if (tid < 2 * G) partial[(((long long)d * gridDim.x + blockIdx.x) * G) * 2 + tid] = gacc;
   // ---- last-arriving block of this domain sums the per-split partials IN FIXED ORDER (bit-reproducible whichever
-  // block is last).  Hand-off per the agent-scope release/acquire recipe (guide G16): every wave drains its stores,
-  // one lane releases and takes a ticket; the last arriver acquires, then plain loads.
+  // block is last).  Hand-off in the write-through form of the agent-scope recipe (guide G16): the 4-byte partials are
+  // sc1 stores (relaxed agent-scope atomic stores -> no L2 write-back fence), every wave drains its stores, one lane
+  // takes a ticket; the last arriver reads the partials with sc1 loads.
+  if (tid < 2 * G)
+    __hip_atomic_store(partial + (((long long)d * gridDim.x + blockIdx.x) * G) * 2 + tid, gacc, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned ticket = __hip_atomic_fetch_add(counters + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (ticket == gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
   if (s_last) {
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
     if (tid < 2 * G) {
       float a = 0.f;
       const float* pp = partial + (long long)d * gridDim.x * G * 2 + tid;
-      for (unsigned sidx = 0; sidx < gridDim.x; ++sidx) a += pp[(long long)sidx * G * 2];
+      for (unsigned sidx = 0; sidx < gridDim.x; ++sidx)
+        a += __hip_atomic_load(pp + (long long)sidx * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out[(long long)d * G * 2 + tid] = a;
     }
     if (tid == 0) counters[d] = 0u;          // re-armed for the next call (stream order makes it visible)
@@ -145,69 +161,100 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------ GroupNorm apply (fwd) / dx (bwd)
+// grid (nsplit, ndomains) like the statistics pass: a thread owns ONE 8-channel chunk column and walks rows, so the
+// per-channel affine terms (mean, rstd, gamma, beta and the backward sums) are formed once in registers and the row loop
+// is pure streaming — four independent 16-byte loads in flight per operand.
 template <bool BWD>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, long long ldx,
                                                         const bf16_t* __restrict__ dy, long long lddy,
-                                                        bf16_t* __restrict__ y, long long ldy, long long nrows,
-                                                        int rows_per_domain, int C, int G, const float* __restrict__ sums,
-                                                        const float* __restrict__ bsums, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps, int silu, float drop_p,
-                                                        unsigned long long drop_seed) {
-  const int tpr = C >> 3, cpg = C / G;
-  const float cnt = (float)rows_per_domain * cpg, icnt = 1.f / cnt;
+                                                        bf16_t* __restrict__ y, long long ldy, int rows_per_domain, int C, int G,
+                                                        const float* __restrict__ sums, const float* __restrict__ bsums,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int silu, float drop_p, unsigned long long drop_seed) {
+  const int d = blockIdx.y, tid = threadIdx.x;
+  const int nchunks = C >> 3;
+  const int tpr = min(nchunks, 256), rpp = 256 / tpr;
+  const int ncb = (nchunks + tpr - 1) / tpr;
+  const int rl = tid / tpr, cpg = C / G;
+  const int rows_per_split = (rows_per_domain + gridDim.x - 1) / gridDim.x;
+  const int rbeg = blockIdx.x * rows_per_split, rend = min(rows_per_domain, rbeg + rows_per_split);
+  const float icnt = 1.f / ((float)rows_per_domain * cpg);
   const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const unsigned nchunks = (unsigned)(nrows * tpr);      // < 2^31 (checked on the host): 32-bit index math, no 64-bit divides
-  for (unsigned ci = blockIdx.x * 256u + threadIdx.x; ci < nchunks; ci += gridDim.x * 256u) {
-    const unsigned urow = ci / (unsigned)tpr;
-    const int cc = (int)(ci - urow * (unsigned)tpr);
-    const int d = (int)(urow / (unsigned)rows_per_domain);
-    const long long row = urow;
-    bf16x8 xv = *(const bf16x8*)(x + row * ldx + cc * 8);
-    bf16x8 gv;
-    if (BWD) gv = *(const bf16x8*)(dy + row * lddy + cc * 8);
-    int gi = (cc * 8) / cpg, rem = (cc * 8) - gi * cpg;
-    float mu = 0.f, rs = 0.f, b1 = 0.f, b2 = 0.f;
-    bool fresh = true;
-    bf16x8 ov;
+  constexpr int UN = 4;
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int cc = cb * tpr + tid % tpr;
+    if (rl >= rpp || cc >= nchunks) continue;
+    float mu[8], rs[8], gm[8], bt[8], b1[8], b2[8];
+    {
+      int gi = (cc * 8) / cpg, rem = (cc * 8) - gi * cpg;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (fresh) {
+      for (int e = 0; e < 8; ++e) {
         const float* sp = sums + ((long long)d * G + gi) * 2;
-        mu = sp[0] * icnt;
-        rs = rsqrtf(fmaxf(sp[1] * icnt - mu * mu, 0.f) + eps);
+        const float m = sp[0] * icnt;
+        mu[e] = m;
+        rs[e] = rsqrtf(fmaxf(sp[1] * icnt - m * m, 0.f) + eps);
+        gm[e] = gamma[cc * 8 + e];
+        bt[e] = beta[cc * 8 + e];
         if (BWD) {
           const float* bp = bsums + ((long long)d * G + gi) * 2;
-          b1 = bp[0] * icnt;
-          b2 = bp[1] * icnt;
+          b1[e] = bp[0] * icnt;
+          b2[e] = bp[1] * icnt;
         }
-        fresh = false;
+        if (++rem == cpg) {
+          rem = 0;
+          ++gi;
+        }
       }
-      const int c = cc * 8 + e;
-      const float xh = (bf2f((unsigned short)xv[e]) - mu) * rs;
-      float out;
       if (!BWD) {
-        float zz = xh * gamma[c] + beta[c];
-        if (silu) zz = silu_f(zz);
-        if (drop_p > 0.f) zz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? zz * ks : 0.f;
-        out = zz;
-      } else {
-        float dz = bf2f((unsigned short)gv[e]);
-        if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? dz * ks : 0.f;
-        if (silu) {
-          float zz = xh * gamma[c] + beta[c];
-          float sg = sigmoid_f(zz);
-          dz *= sg * (1.f + zz * (1.f - sg));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {     // y = x * sc + sh
+          gm[e] *= rs[e];
+          bt[e] -= mu[e] * gm[e];
         }
-        out = rs * (dz * gamma[c] - b1 - xh * b2);
-      }
-      ov[e] = (short)f2bf(out);
-      if (++rem == cpg) {
-        rem = 0;
-        ++gi;
-        fresh = true;
       }
     }
-    *(bf16x8*)(y + row * ldy + cc * 8) = ov;
+    const long long base = (long long)d * rows_per_domain;
+    for (int r = rbeg + rl; r < rend; r += UN * rpp) {
+      bf16x8 xv[UN], gv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int rr = r + u * rpp;
+        if (rr < rend) {
+          xv[u] = *(const bf16x8*)(x + (base + rr) * ldx + cc * 8);
+          if (BWD) gv[u] = *(const bf16x8*)(dy + (base + rr) * lddy + cc * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int rr = r + u * rpp;
+        if (rr >= rend) continue;
+        const long long row = base + rr;
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = cc * 8 + e;
+          float out;
+          if (!BWD) {
+            float zz = bf2f((unsigned short)xv[u][e]) * gm[e] + bt[e];
+            if (silu) zz = silu_f(zz);
+            if (drop_p > 0.f) zz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? zz * ks : 0.f;
+            out = zz;
+          } else {
+            const float xh = (bf2f((unsigned short)xv[u][e]) - mu[e]) * rs[e];
+            float dz = bf2f((unsigned short)gv[u][e]);
+            if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? dz * ks : 0.f;
+            if (silu) {
+              const float zz = xh * gm[e] + bt[e];
+              const float sg = sigmoid_f(zz);
+              dz *= sg * (1.f + zz * (1.f - sg));
+            }
+            out = rs[e] * (dz * gm[e] - b1[e] - xh * b2[e]);
+          }
+          ov[e] = (short)f2bf(out);
+        }
+        *(bf16x8*)(y + row * ldy + cc * 8) = ov;
+      }
+    }
   }
 }
 
@@ -340,10 +387,16 @@ int gn_check(const char* fn, int C, int G, long long ldx) {
   }
   return T2V_OK;
 }
+// row slabs of the apply passes: >= 8 rows per thread, up to ~2048 blocks (no cross-block reduction, so no split cap)
+int gn_apply_splits(int ndomains, int rows_per_domain, int C) {
+  int rpp = 256 / min(C >> 3, 256);
+  int want = max(1, 2048 / max(1, ndomains));
+  return max(1, min(want, rows_per_domain / (rpp * 8)));
+}
 int gn_splits(int ndomains, int rows_per_domain, int C) {
   int rpp = 256 / min(C >> 3, 256);
   int want = max(1, 2048 / max(1, ndomains));
-  int maxs = max(1, rows_per_domain / (rpp * 4));
+  int maxs = max(1, rows_per_domain / (rpp * 8));
   return max(1, min(GN_MAX_SPLIT, min(want, maxs)));
 }
 }  // namespace
@@ -376,13 +429,10 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
                             float drop_p, unsigned long long drop_seed, t2v_stream_t stream) {
   if (int e = gn_check("t2v_gn_apply", C, G, ldx)) return e;
   T2V_CHECK_ARG(x && y && sums && gamma && beta && ldy % 8 == 0, "t2v_gn_apply: bad args");
-  long long nrows = (long long)ndomains * rows_per_domain;
-  long long nchunks = nrows * (C >> 3);
-  T2V_CHECK_ARG(nchunks < (1LL << 31), "t2v_gn_apply: tensor too large for 32-bit chunk indexing");
-  int grid = (int)min((nchunks + 255) / 256, (long long)8192);
-  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
-                     0, (bf16_t*)y, ldy, nrows, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p,
-                     drop_seed);
+  T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_apply: bad domain grid");
+  dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
+  hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
+                     0, (bf16_t*)y, ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -412,12 +462,10 @@ extern "C" int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, lo
   if (int e = gn_check("t2v_gn_bwd_apply", C, G, ldx)) return e;
   T2V_CHECK_ARG(x && dy && dx && sums && bsums && gamma && beta && lddy % 8 == 0 && lddx % 8 == 0,
                 "t2v_gn_bwd_apply: bad args");
-  long long nrows = (long long)ndomains * rows_per_domain;
-  long long nchunks = nrows * (C >> 3);
-  T2V_CHECK_ARG(nchunks < (1LL << 31), "t2v_gn_bwd_apply: tensor too large for 32-bit chunk indexing");
-  int grid = (int)min((nchunks + 255) / 256, (long long)8192);
-  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                     (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nrows, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,
+  T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_bwd_apply: bad domain grid");
+  dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
+  hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,
                      silu, drop_p, drop_seed);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
