@@ -166,7 +166,7 @@ int t2v_softmax_rows(const void* x, long long ldx, void* y, long long ldy, long 
 int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long long rows, int cols, float p,
                      unsigned long long seed, t2v_stream_t stream);
 
-/* rank-r update y[m,n] += scale * sum_j t[m,j] * U[j,n]  (bf16, r in {8,16,24,32}) — the LoRA up-projection
+/* rank-r update y[m,n] += scale * sum_j t[m,j] * U[j,n]  (bf16, r in {8,16,24,32,48,64,96}) — the LoRA up-projection
  * `lora_up(lora_down(x)) * scale` added onto the base layer's output (utils/lora.py:57-62) and the linear case of its
  * backward dx += dt D, as an HBM-bound streaming pass. */
 int t2v_lowrank_update(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M, int N,

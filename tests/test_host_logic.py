@@ -178,3 +178,63 @@ def test_stable_lora_flavour_cpu_semantics(tmp_path):
     SL.load_lora(m, str(f))
     after = SL.lora_state_dict(m)
     assert any(not torch.equal(before[k], after[k]) for k in before)      # saved zeros for lora_B were restored
+
+
+def test_lora_bank_projection_groups():
+    """to_q/to_k/to_v sharing an input are stored as one group: downs back to back ([3rp, Cin]), ups as the block-diagonal
+    [3rp, 3N] matrix (member i = row block i, column block i; the rest structurally zero), Parameters still module-shaped."""
+    import t2v_amd.lora_bank as lb
+    from t2v_amd.utils import lora as L
+
+    class Attn(torch.nn.Module):
+        def __init__(self, dim, kv):
+            super().__init__()
+            self.to_q = L.LoraInjectedLinear(dim, dim, bias=False, r=4)
+            self.to_k = L.LoraInjectedLinear(kv, dim, bias=False, r=4)
+            self.to_v = L.LoraInjectedLinear(kv, dim, bias=False, r=4)
+
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict(dict(selfa=Attn(24, 24), cross=Attn(24, 40), other=L.LoraInjectedLinear(24, 8, r=4)))
+    for m in model.modules():
+        if hasattr(m, "lora_up"):
+            torch.nn.init.normal_(m.lora_up.weight)
+    params = [p for n, p in model.named_parameters() if "lora_" in n]
+    plans = lb.plan(model)
+    gs, gc = model["selfa"]._t2v_group, model["cross"]._t2v_group
+    assert gs.n == 3 and gc.n == 2 and gc.mods[0] is model["cross"].to_k
+    assert (gs.rp, gs.npad, gs.cin_p) == (24, 72, 24) and (gc.rp, gc.npad, gc.cin_p) == (16, 48, 40)
+    plist = lb.reorder(params, plans)
+    assert len(plist) == len(params) and {id(p) for p in plist} == {id(p) for p in params}
+    sizes = []
+    for p in plist:
+        e, role, _ = plans[id(p)]
+        sizes.append(((e.down_numel if role == "down" else e.up_numel) + 7) // 8 * 8)
+    flat, flat16, flatg = torch.zeros(sum(sizes)), torch.zeros(sum(sizes), dtype=torch.bfloat16), torch.zeros(sum(sizes))
+    off, offsets = 0, {}
+    for p, k in zip(plist, sizes):
+        e, role, _ = plans[id(p)]
+        v = lb.param_view(flat[off:off + k], p, e, role)
+        assert v.shape == p.shape
+        v.copy_(p.detach())
+        offsets[id(p)] = off
+        off += k
+    flat16.copy_(flat)
+    lb.attach(plans, flat16, flatg, offsets)
+    for g in (gs, gc):
+        n, rp, npad = g.n, g.rp_each, g.npad_each
+        dcat = torch.cat([torch.nn.functional.pad(m.lora_down.weight.detach(), (0, 0, 0, rp - 4)) for m in g.mods], 0)
+        assert torch.equal(g.down_w16.float(), dcat.bfloat16().float())
+        ublk = torch.zeros(g.rp, g.npad)
+        for i, m in enumerate(g.mods):
+            ublk[i * rp: i * rp + 4, i * npad: i * npad + 24] = m.lora_up.weight.detach().t()
+        assert torch.equal(g.up_w16.float(), ublk.bfloat16().float())
+        for i, m in enumerate(g.mods):       # the per-member views used by the unfused path address the same storage
+            e = m._t2v_bank
+            assert e.up_w16.shape == (rp, npad) and e.up_w16.stride(0) == g.npad
+            assert torch.equal(e.up_w16.float(), ublk[i * rp:(i + 1) * rp, i * npad:(i + 1) * npad].bfloat16().float())
+            assert e.up_g.data_ptr() == g.up_g.data_ptr() + (i * rp * g.npad + i * npad) * 4
+    # a partially trained group falls apart into ordinary layers
+    plans2 = lb.plan(model)
+    keep = [p for p in params if p is not model["selfa"].to_k.lora_up.weight]
+    lb.reorder(keep, plans2)
+    assert "_t2v_group" not in model["selfa"].__dict__ and plans2[id(model["selfa"].to_q.lora_up.weight)][0].group is None

@@ -386,7 +386,8 @@ extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long lo
                                   int N, int r, float scale, t2v_stream_t s) {
   T2V_CHECK_ARG(y && t && U && M > 0 && N > 0 && N % 8 == 0 && ldy % 8 == 0 && ldt % 8 == 0 && ldu % 8 == 0,
                 "t2v_lowrank_update: bad args");
-  T2V_CHECK_ARG(r == 8 || r == 16 || r == 24 || r == 32, "t2v_lowrank_update: rank must be 8, 16, 24 or 32 (got %d)", r);
+  T2V_CHECK_ARG(r == 8 || r == 16 || r == 24 || r == 32 || r == 48 || r == 64 || r == 96,
+                "t2v_lowrank_update: rank must be 8, 16, 24, 32, 48, 64 or 96 (got %d)", r);
   const int ncb = (N + 127) / 128;
   long long want_blocks = 2048;
   int rpb = (int)std::max<long long>(64, ((M * ncb + want_blocks - 1) / want_blocks + 63) / 64 * 64);
@@ -397,7 +398,10 @@ extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long lo
   if (r == 8) T2V_LRU(8);
   else if (r == 16) T2V_LRU(16);
   else if (r == 24) T2V_LRU(24);
-  else T2V_LRU(32);
+  else if (r == 32) T2V_LRU(32);
+  else if (r == 48) T2V_LRU(48);
+  else if (r == 64) T2V_LRU(64);
+  else T2V_LRU(96);
 #undef T2V_LRU
   T2V_CHECK_LAUNCH();
   return T2V_OK;

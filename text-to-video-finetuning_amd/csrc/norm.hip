@@ -9,7 +9,7 @@ namespace {
 // ------------------------------------------------------------------ GroupNorm statistics
 // grid (nsplit, ndomains); each block reduces a slab of rows of one domain over all channels and writes its
 // per-group partial (no atomics: fixed-order LDS reduction + a finalize pass => bit-reproducible statistics).
-constexpr int GN_MAX_SPLIT = 64;
+constexpr int GN_MAX_SPLIT = 256;
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, long long ldx,
@@ -149,12 +149,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   }
   __syncthreads();
   if (s_last) {
-    if (tid < 2 * G) {
-      float a = 0.f;
-      const float* pp = partial + (long long)d * gridDim.x * G * 2 + tid;
-      for (unsigned sidx = 0; sidx < gridDim.x; ++sidx)
-        a += __hip_atomic_load(pp + (long long)sidx * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out[(long long)d * G * 2 + tid] = a;
+    // 256 threads = (2G statistics) x nparts slices of the split range; every thread sums its slice in index order with
+    // 8 loads in flight, then the slices are combined in slice order: a fixed association whichever block is last.
+    const int nst = 2 * G, nparts = max(1, 256 / nst);
+    const int v = tid % nst, part = tid / nst;
+    float a = 0.f;
+    if (part < nparts) {
+      const unsigned per = (gridDim.x + nparts - 1) / nparts;
+      const unsigned sb = part * per, se = min(gridDim.x, sb + per);
+      const float* pp = partial + (long long)d * gridDim.x * G * 2 + v;
+      for (unsigned s0 = sb; s0 < se; s0 += 8) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          vv[u] = (s0 + u < se) ? __hip_atomic_load(pp + (long long)(s0 + u) * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += vv[u];
+      }
+    }
+    sval[tid] = a;
+    __syncthreads();
+    if (tid < nst) {
+      float tot = 0.f;
+      for (int q = 0; q < nparts; ++q) tot += sval[q * nst + tid];
+      out[(long long)d * G * 2 + tid] = tot;
     }
     if (tid == 0) counters[d] = 0u;          // re-armed for the next call (stream order makes it visible)
   }

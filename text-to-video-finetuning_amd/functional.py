@@ -329,8 +329,8 @@ def join_side_stream():
 
 
 def _lowrank_update(y, t, u, M, N, r, scale):
-    """y[M,N] += scale * t[M,r] @ u[r,N] (streaming rank-r update kernel; falls back to the GEMM for ranks > 32)."""
-    if r in (8, 16, 24, 32):
+    """y[M,N] += scale * t[M,r] @ u[r,N] (streaming rank-r update kernel; other ranks go through the GEMM)."""
+    if r in (8, 16, 24, 32, 48, 64, 96):
         nv.call("t2v_lowrank_update", y.data_ptr(), _ld(y), t.data_ptr(), _ld(t), u.data_ptr(), _ld(u), M, N, r, scale,
                 nv.stream())
     else:
@@ -396,12 +396,12 @@ class _LoraLayer(torch.autograd.Function):
             wb = prepared_weight(w_base, "bwd")
             dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
             launch_gemm(M=M, N=cin_p + e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
-                        D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=npad, n_split=cin_p, D2=dt.data_ptr(),
-                        ldd2=e.rp)
+                        D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p,
+                        D2=dt.data_ptr(), ldd2=e.rp)
             _lowrank_update(dx, dt, e.down_w16, M, cin_p, e.rp, scale)           # dx += s dt D
         else:
-            launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=npad, D=dt.data_ptr(),
-                        ldd=e.rp)
+            launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16),
+                        D=dt.data_ptr(), ldd=e.rp)
             if need_dx:
                 wb = prepared_weight(w_base, "bwd")
                 Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
@@ -428,7 +428,7 @@ class _LoraLayer(torch.autograd.Function):
                 w = nv.LoraWgrad()
                 w.rows, w.rp, w.conv = M, e.rp, 1 if conv else 0
                 w.t, w.ldt, w.dy, w.lddy, w.N = t.data_ptr(), _ld(t), dy.data_ptr(), _ld(dy), npad
-                w.dU, w.lddu = e.up_g.data_ptr(), npad
+                w.dU, w.lddu = e.up_g.data_ptr(), _ld(e.up_g)
                 w.dt, w.lddt, w.x, w.ldx, w.C = dt.data_ptr(), _ld(dt), x.data_ptr(), _ld(x), cin_p
                 w.dD, w.lddd = e.down_g.data_ptr(), kw
                 if conv:
@@ -438,7 +438,7 @@ class _LoraLayer(torch.autograd.Function):
                 return
             launch_gemm_pair(     # strided / resampled windows: two K-major GEMMs in one launch
                 dict(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy.data_ptr(), ldb=_ld(dy), b_trans=1,
-                     D=e.up_g.data_ptr(), ldd=npad, out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
+                     D=e.up_g.data_ptr(), ldd=_ld(e.up_g), out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
                      split_k=_split_k((npad + 63) // 64, M)),
                 dict(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
                      b_conv=1 if conv else 0, geom=g, D=e.down_g.data_ptr(), ldd=kw,
@@ -453,6 +453,113 @@ class _LoraLayer(torch.autograd.Function):
         else:
             wgrads()
         return dx, None, None, None, None, drb, dres, None, None, None
+
+
+def _group_weight(ws, kind):
+    """Concatenated bf16 GEMM-layout copy of the (frozen) base weights of a projection group, cached on the first member:
+    fwd [n*Np, K] (rows = outputs of all members), bwd [Kin_p, n*Np]."""
+    w0 = ws[0]
+    tag = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in ws)
+    cache = w0.__dict__.setdefault("_t2v_prep", {})
+    hit = cache.get(("group", kind))
+    if hit is None or hit[0] != tag:
+        parts = [prepared_weight(w, kind) for w in ws]
+        hit = (tag, torch.cat(parts, dim=0 if kind == "fwd" else 1).contiguous())
+        cache[("group", kind)] = hit
+    return hit[1]
+
+
+def _adjacent_columns(ts):
+    """True if the 2-D tensors are consecutive, equally wide column blocks of one row-major buffer."""
+    t0 = ts[0]
+    if any(t.dim() != 2 or t.dtype != t0.dtype or t.shape != t0.shape or t.stride() != t0.stride() for t in ts):
+        return False
+    w = t0.shape[1]
+    if t0.stride(1) != 1 or t0.stride(0) < w * len(ts):
+        return False
+    return all(t.data_ptr() == t0.data_ptr() + i * w * t0.element_size() for i, t in enumerate(ts))
+
+
+def column_blocks(rows, width, n, device):
+    """n column blocks [rows, width] of one fresh [rows, n*width] bf16 buffer (what `_LoraGroup.backward` can consume
+    without a concatenation copy)."""
+    buf = torch.empty(rows, n * width, dtype=BF16, device=device)
+    return [buf[:, i * width:(i + 1) * width] for i in range(n)]
+
+
+class _LoraGroup(torch.autograd.Function):
+    """Projections sharing one input (to_q/to_k/to_v, or to_k/to_v of the text cross-attention), each LoRA-wrapped, as ONE
+    layer: [y_0 | .. | y_{n-1} | t] = x [W_0; ..; W_{n-1}; D_cat]^T, y += s t U_blk (U_blk block-diagonal, lora_bank.py);
+    backward [dx | dt] = [dy_0 | .. ] [W_cat^T | U_blk^T], dx += s dt D_cat, factor gradients per member."""
+
+    @staticmethod
+    def forward(ctx, x, g, scale, *w_bases):
+        x = _mat(x, "x")
+        n = g.n
+        wq = _group_weight(w_bases, "fwd")
+        ncat, K = wq.shape
+        if x.shape[1] != K or ncat != g.npad or K != g.cin_p:
+            raise RuntimeError("t2v_amd: projection group does not match its layers")
+        M = x.shape[0]
+        y = torch.empty(M, ncat, dtype=BF16, device=x.device)
+        t = torch.empty(M, g.rp, dtype=BF16, device=x.device)
+        launch_gemm(M=M, N=ncat + g.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=ncat,
+                    B2=g.down_w16.data_ptr(), ldb2=K, n_split=ncat, D2=t.data_ptr(), ldd2=g.rp)
+        _lowrank_update(y, t, g.up_w16, M, ncat, g.rp, scale)
+        ctx.g, ctx.scale = g, scale
+        ctx.save_for_backward(x, t, *w_bases)
+        return tuple(y[:, i * g.npad_each:(i + 1) * g.npad_each] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, t = ctx.saved_tensors[:2]
+        w_bases = ctx.saved_tensors[2:]
+        g, scale = ctx.g, ctx.scale
+        n, M = g.n, x.shape[0]
+        if any(d is None for d in dys):
+            dys = [d if d is not None else torch.zeros(M, g.npad_each, dtype=BF16, device=x.device) for d in dys]
+        if _adjacent_columns(dys):
+            dy_ptr, lddy = dys[0].data_ptr(), dys[0].stride(0)
+            keep = dys
+        else:
+            dcat = torch.cat([_mat(d if d.stride(1) == 1 else d.contiguous(), "dy") for d in dys], dim=1)
+            dy_ptr, lddy = dcat.data_ptr(), dcat.stride(0)
+            keep = (dcat,)
+        wb = _group_weight(w_bases, "bwd")
+        cin_p, ncat = g.cin_p, g.npad
+        dx = torch.empty(M, cin_p, dtype=BF16, device=x.device)
+        dt = torch.empty(M, g.rp, dtype=BF16, device=x.device)
+        launch_gemm(M=M, N=cin_p + g.rp, K=ncat, A=dy_ptr, lda=lddy, B=wb.data_ptr(), ldb=ncat, D=dx.data_ptr(), ldd=cin_p,
+                    B2=g.up_w16.data_ptr(), ldb2=ncat, n_split=cin_p, D2=dt.data_ptr(), ldd2=g.rp)
+        _lowrank_update(dx, dt, g.down_w16, M, cin_p, g.rp, scale)
+        rpe, npe = g.rp_each, g.npad_each
+
+        def wgrads():
+            for i in range(n):
+                w = nv.LoraWgrad()
+                w.rows, w.rp, w.conv = M, rpe, 0
+                w.t, w.ldt = t.data_ptr() + i * rpe * 2, g.rp
+                w.dy, w.lddy, w.N = dy_ptr + i * npe * 2, lddy, npe
+                w.dU, w.lddu = g.up_g.data_ptr() + (i * rpe * ncat + i * npe) * 4, ncat
+                w.dt, w.lddt = dt.data_ptr() + i * rpe * 2, g.rp
+                w.x, w.ldx, w.C = x.data_ptr(), _ld(x), cin_p
+                w.dD, w.lddd = g.down_g.data_ptr() + i * rpe * cin_p * 4, cin_p
+                w.alpha = scale
+                nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+
+        if _side["enabled"]:
+            side = _side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                wgrads()
+            _side["refs"].append((keep, t, dt, x))
+        else:
+            wgrads()
+        return (dx, None, None) + (None,) * n
+
+
+def lora_group(x, group, scale, w_bases):
+    return _LoraGroup.apply(x, group, float(scale), *w_bases)
 
 
 def _wgrad_window_ok(g, rows):
@@ -599,7 +706,11 @@ class _Attention(torch.autograd.Function):
         heads, qlay, klay, scale = ctx.meta
         do = _mat(do if do.stride(1) == 1 else do.contiguous(), "do")
         width = heads * 64
-        dq = torch.empty(q.shape[0], width, dtype=BF16, device=q.device)
+        fused_qkv = _adjacent_columns((q, k, v))
+        if fused_qkv:       # q, k, v came out of one fused projection: lay the gradients out the same way (no concat copy)
+            dq, dk_, dv_ = column_blocks(q.shape[0], width, 3, q.device)
+        else:
+            dq = torch.empty(q.shape[0], width, dtype=BF16, device=q.device)
         # text cross-attention shares one K/V across the frames of a video (klay.lo == 0, bdiv = frames):
         # dK/dV are produced per query batch and summed over the sharing group below
         shared = klay.bdiv > 1 and klay.lo == 0
@@ -608,8 +719,13 @@ class _Attention(torch.autograd.Function):
             dv = torch.empty_like(dk)
             dklay = SeqLayout(qlay.nbatch, klay.S, klay.S, 0, 1, 1)
         else:
-            dk = torch.empty(k.shape[0], width, dtype=BF16, device=q.device)
-            dv = torch.empty_like(dk)
+            if fused_qkv:
+                dk, dv = dk_, dv_
+            elif _adjacent_columns((k, v)):
+                dk, dv = column_blocks(k.shape[0], width, 2, q.device)
+            else:
+                dk = torch.empty(k.shape[0], width, dtype=BF16, device=q.device)
+                dv = torch.empty_like(dk)
             dklay = klay
         delta = torch.empty_like(lse)
         a = nv.Attn()

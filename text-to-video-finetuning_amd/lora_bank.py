@@ -9,6 +9,13 @@ factor is stored in the flat fp32 parameter buffer DIRECTLY in the layout the GE
   * one cast kernel per step refreshes the bf16 copies of ALL factors (no per-layer permute/cast launches),
   * weight gradients are accumulated by the TN GEMM straight into the flat fp32 gradient buffer (no per-layer
     zeros / un-permute / AccumulateGrad launches), where clip + AdamW + the RCCL all-reduce operate.
+
+Projection groups.  `to_q/to_k/to_v` of a self-attention (and `to_k/to_v` of the text cross-attention) read the same
+input, so they are evaluated as ONE GEMM (models/leaves.py::Attention).  Their factors are stored adjacently:
+  downs  [n*rp, Cin_p]          = the members' down slots back to back            (D_cat)
+  ups    [n*rp, n*Np]           member i owns the row block [i*rp, (i+1)*rp) — its slot — and, inside it, the column block
+                                [i*Np, (i+1)*Np); the rest of the slot is structurally zero (never receives a gradient),
+                                so the whole region IS the block-diagonal up matrix the fused launches consume.
 """
 import torch
 
@@ -17,7 +24,45 @@ from .functional import ceil8
 
 class LoraEntry:
     __slots__ = ("r", "rp", "n", "npad", "cin", "cin_p", "taps", "down_off", "up_off", "down_numel", "up_numel",
-                 "down_w16", "up_w16", "down_g", "up_g", "flat_ptr")
+                 "down_w16", "up_w16", "down_g", "up_g", "flat_ptr", "group", "gidx")
+
+
+class LoraGroup:
+    """Projections that share their input (see module docstring).  `n` members of equal (rp, Np, Cin_p)."""
+    __slots__ = ("entries", "mods", "owner", "n", "rp_each", "rp", "npad_each", "npad", "cin_p", "down_w16", "up_w16", "down_g",
+                 "up_g")
+
+
+def _dissolve(g):
+    for e in g.entries:
+        e.group, e.gidx = None, 0
+        e.up_numel = e.npad * e.rp
+    g.owner.__dict__.pop("_t2v_group", None)
+
+
+def _find_groups(model, plans):
+    """[(attention_module, [wrapper modules])]: q,k,v (same input width) or k,v of every module exposing to_q/to_k/to_v."""
+    out = []
+    for mod in model.modules():
+        names = ("to_q", "to_k", "to_v")
+        if not all(hasattr(mod, a) for a in names):
+            continue
+        ws = [getattr(mod, a) for a in names]
+        ents = []
+        for w in ws:
+            parts = _wrapper_parts(w)
+            pl = plans.get(id(parts[1].weight)) if parts is not None else None
+            ents.append(pl[0] if pl is not None and pl[2] is w else None)
+        if any(e is None or e.taps != 1 for e in ents):
+            continue
+        if any(_wrapper_parts(w)[0].bias is not None for w in ws):
+            continue
+        same = lambda a, b: (a.rp, a.npad, a.cin_p, a.r) == (b.rp, b.npad, b.cin_p, b.r)
+        if same(ents[0], ents[1]) and same(ents[1], ents[2]):
+            out.append((mod, ws))
+        elif same(ents[1], ents[2]):
+            out.append((mod, ws[1:]))
+    return out
 
 
 def _wrapper_parts(mod):
@@ -29,11 +74,13 @@ def _wrapper_parts(mod):
     return base, mod.lora_down, mod.lora_up
 
 
-def plan(model):
-    """Map id(param) -> (entry, 'down'|'up') for every cloneofsimo-style wrapper in `model`."""
+def plan(model, fuse_groups=True):
+    """Map id(param) -> (entry, 'down'|'up', wrapper) for every cloneofsimo-style wrapper in `model`."""
     plans = {}
     if model is None:
         return plans
+    for mod in model.modules():
+        mod.__dict__.pop("_t2v_group", None)
     for mod in model.modules():
         parts = _wrapper_parts(mod)
         if parts is None:
@@ -54,9 +101,49 @@ def plan(model):
             continue    # only the (k,1,1) temporal conv is a supported 3-D window
         e.down_numel = e.rp * e.taps * e.cin_p
         e.up_numel = e.npad * e.rp
+        e.group, e.gidx = None, 0
         plans[id(wd)] = (e, "down", mod)
         plans[id(wu)] = (e, "up", mod)
+    if fuse_groups:
+        for attn, ws in _find_groups(model, plans):
+            g = LoraGroup()
+            g.mods, g.owner = ws, attn
+            g.entries = [plans[id(w.lora_down.weight)][0] for w in ws]
+            g.n = len(ws)
+            e0 = g.entries[0]
+            g.rp_each, g.rp, g.npad_each, g.npad, g.cin_p = e0.rp, e0.rp * g.n, e0.npad, e0.npad * g.n, e0.cin_p
+            if g.rp > 96:
+                continue
+            for i, e in enumerate(g.entries):
+                e.group, e.gidx = g, i
+                e.up_numel = e.rp * g.npad            # the member's slot is a full row block of the group's up matrix
+            attn._t2v_group = g
     return plans
+
+
+def reorder(plist, plans):
+    """Parameter order of the flat buffer: group members' downs back to back, then their ups back to back (member order)."""
+    by_id = {id(p): p for p in plist}
+    emitted, out = set(), []
+    for p in plist:
+        if id(p) in emitted:
+            continue
+        pl = plans.get(id(p))
+        g = pl[0].group if pl else None
+        if g is None:
+            out.append(p)
+            emitted.add(id(p))
+            continue
+        members = [w.lora_down.weight for w in g.mods] + [w.lora_up.weight for w in g.mods]
+        if not all(id(m) in by_id for m in members):      # partially trained group: evaluate its members one by one
+            _dissolve(g)
+            out.append(p)
+            emitted.add(id(p))
+            continue
+        for m in members:
+            out.append(m)
+            emitted.add(id(m))
+    return out
 
 
 def param_view(flat_slice, p, entry, role):
@@ -71,7 +158,11 @@ def param_view(flat_slice, p, entry, role):
                 flat_slice.view(entry.rp, p.shape[2], p.shape[3], entry.cin_p)[: entry.r, :, :, : entry.cin].permute(0, 3, 1, 2)
         v = s3.permute(0, 2, 1)
         return v[:, :, :, None, None]
-    s2 = flat_slice.view(entry.rp, entry.npad)[: entry.r, : entry.n].t()
+    if entry.group is not None:
+        c0 = entry.gidx * entry.npad
+        s2 = flat_slice.view(entry.rp, entry.group.npad)[: entry.r, c0: c0 + entry.n].t()
+    else:
+        s2 = flat_slice.view(entry.rp, entry.npad)[: entry.r, : entry.n].t()
     for _ in range(p.dim() - 2):
         s2 = s2.unsqueeze(-1)
     return s2
@@ -90,10 +181,30 @@ def attach(plans, flat_p16, flat_g, offsets):
             e.down_g = flat_g[off: off + e.down_numel].view(e.rp, e.taps * e.cin_p)
         else:
             e.up_off = off
-            e.up_w16 = flat_p16[off: off + e.up_numel].view(e.rp, e.npad)
-            e.up_g = flat_g[off: off + e.up_numel].view(e.rp, e.npad)
+            if e.group is not None:     # column block of the member's row-block slot (leading dimension = group width)
+                c0 = e.gidx * e.npad
+                e.up_w16 = flat_p16[off: off + e.up_numel].view(e.rp, e.group.npad)[:, c0: c0 + e.npad]
+                e.up_g = flat_g[off: off + e.up_numel].view(e.rp, e.group.npad)[:, c0: c0 + e.npad]
+            else:
+                e.up_w16 = flat_p16[off: off + e.up_numel].view(e.rp, e.npad)
+                e.up_g = flat_g[off: off + e.up_numel].view(e.rp, e.npad)
         done.add(id(mod))
+    groups = {}
     for pid, (e, role, mod) in plans.items():
         if all(hasattr(e, a) for a in ("down_w16", "up_w16")):
             e.flat_ptr = flat_g.data_ptr()
             mod._t2v_bank = e
+            if e.group is not None:
+                groups[id(e.group)] = e.group
+    for g in groups.values():
+        es = g.entries
+        ok = all(hasattr(e, "down_off") and hasattr(e, "up_off") for e in es)
+        for a, b in zip(es, es[1:]):
+            ok = ok and b.down_off == a.down_off + a.down_numel and b.up_off == a.up_off + a.up_numel
+        if not ok:
+            raise RuntimeError("t2v_amd: fused projection group is not contiguous in the flat buffer")
+        d0, u0 = es[0].down_off, es[0].up_off
+        g.down_w16 = flat_p16[d0: d0 + g.rp * g.cin_p].view(g.rp, g.cin_p)
+        g.down_g = flat_g[d0: d0 + g.rp * g.cin_p].view(g.rp, g.cin_p)
+        g.up_w16 = flat_p16[u0: u0 + g.rp * g.npad].view(g.rp, g.npad)
+        g.up_g = flat_g[u0: u0 + g.rp * g.npad].view(g.rp, g.npad)

@@ -235,11 +235,33 @@ class Attention(nn.Module):
     def set_processor(self, processor):   # train.py:138-139 — accepted; the native core is always used on device
         self.processor = processor
 
+    def _fused_group(self, self_attention):
+        """The projection group prepared by the trainer (lora_bank.py) if it can be used for this call: q,k,v for
+        self-attention, k,v when keys/values come from another sequence; same conditions as run_layer's fused path."""
+        g = self.__dict__.get("_t2v_group")
+        if g is None or not torch.is_grad_enabled() or g.n != (3 if self_attention else 2):
+            return None
+        for m in g.mods:
+            base = m.linear
+            sel = getattr(m, "selector", None)
+            if (_drop_p(getattr(m, "dropout", None)) != 0.0 or base.weight.requires_grad or base.bias is not None
+                    or not (sel is None or isinstance(sel, nn.Identity)) or float(m.scale) != float(g.mods[0].scale)
+                    or getattr(m, "_t2v_bank", None) is None):
+                return None
+        return g
+
     def forward(self, x, qlay, ctx=None, klay=None, residual=None):
         src = x if ctx is None else ctx
-        q = run_layer(self.to_q, x)
-        k = run_layer(self.to_k, src)
-        v = run_layer(self.to_v, src)
+        g = self._fused_group(ctx is None)
+        if g is not None and ctx is None:
+            q, k, v = F.lora_group(x, g, g.mods[0].scale, [m.linear.weight for m in g.mods])
+        elif g is not None:
+            q = run_layer(self.to_q, x)
+            k, v = F.lora_group(src, g, g.mods[0].scale, [m.linear.weight for m in g.mods])
+        else:
+            q = run_layer(self.to_q, x)
+            k = run_layer(self.to_k, src)
+            v = run_layer(self.to_v, src)
         o = F.attention(q, k, v, self.heads, qlay, qlay if klay is None else klay, self.scale)
         return run_layer(self.to_out[0], o, residual=residual)
 

@@ -64,6 +64,8 @@ class FlatAdamW:
         self.params = plist
         self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
         plans = lora_bank.plan(model)
+        plist = lora_bank.reorder(plist, plans)
+        self.params = plist
         sizes = []
         for p in plist:
             pl = plans.get(id(p))
