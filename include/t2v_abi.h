@@ -90,6 +90,10 @@ typedef struct {
    * B[n=c, k=(tap', j)] = W[j, taps-1-tap', c]  (backward-data of a LoRA down conv without a transposed copy);
    * uses geom.C (= r) and geom.KH*geom.KW of the A gather. */
   int b_tapflip;
+  /* optional K window of the second weight block: B2 row j holds K indices [b2_k0, b2_k0 + b2_klen) only (B2[j][k - b2_k0]),
+   * zero elsewhere — a 1x1 projection riding in a windowed (conv gather) launch reads only the tap whose gathered row is
+   * the row itself: `dt = dy U` inside the backward-data launch of a stride-1 conv.  b2_klen <= 0: B2 rows span all of K. */
+  int b2_k0, b2_klen;
   /* optional caller-owned fp32 scratch (>= M*N*4 bytes): lets the library split K across workgroups for deep-K launches
    * with few output tiles (partials are accumulated in the scratch, a finalize pass applies the epilogue).
    * ws_split is internal (set 0). */
@@ -132,13 +136,17 @@ int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long ldd
 int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
                      int ndomains, int rows_per_domain, int C, int G, const float* sums, const float* bsums,
                      const float* gamma, const float* beta, float eps, int silu,
-                     float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
+                     float drop_p, unsigned long long drop_seed, const void* addend, long long ldadd, t2v_stream_t stream);
+/* `addend` (bf16 [rows, C], may be NULL) is added to dx: the gradient arriving through a pass-through use of x — the
+ * residual branch `x + f(norm(x))` of ResnetBlock2D / TemporalConvLayer / the transformers — so that the sum autograd
+ * would do in a separate pass rides in this one.  Same for t2v_layernorm_bwd. */
 
 /* ---- LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3).  stats: fp32 [rows,2] = (mean, rstd). */
 int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int C, const float* gamma,
                       const float* beta, float eps, float* stats, t2v_stream_t stream);
 int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int rows,
-                      int C, const float* gamma, const float* stats, float* dgamma, float* dbeta, t2v_stream_t stream);
+                      int C, const float* gamma, const float* stats, float* dgamma, float* dbeta, const void* addend,
+                      long long ldadd, t2v_stream_t stream);
 
 /* ---- scaled-dot-product attention core, head_dim 64, no mask (AttnProcessor2_0, train.py:138-139).
  * One kernel serves temporal self (S=F, strided over frames), spatial self (S=H*W) and cross (Sk=77)
@@ -171,6 +179,12 @@ int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long 
  * backward dx += dt D, as an HBM-bound streaming pass. */
 int t2v_lowrank_update(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M, int N,
                        int r, float scale, t2v_stream_t stream);
+
+/* windowed rank-r update y[q, c] += scale * sum_tap sum_j t[p(q,tap), j] * D[j, tap*N + c]  (r in {8,16,24,32}; stride-1
+ * same-size window of 3 or 9 taps, p(q,tap) as in T2VLoraWgrad) — the backward-data of a LoRA down conv, `dx += dt (*) D^T`
+ * (autograd of utils/lora.py:134-139,211-216), streaming over dx with the window applied to the rank-wide operand. */
+int t2v_lowrank_window_update(void* y, long long ldy, const void* t, long long ldt, const void* D, long long ldd,
+                              const T2VConvGeom* geom, long long M, int N, int r, float scale, t2v_stream_t stream);
 
 /* ---- LoRA factor gradients of one layer in one streaming launch (the weight-gradient half of
  * LoraInjectedLinear/Conv2d/Conv3d, utils/lora.py:57-62,134-139,211-216, as autograd derives it):

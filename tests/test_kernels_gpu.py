@@ -298,3 +298,63 @@ def test_lora_wgrad(nimg, H, W, KH, KW, C, N, rp):
     eu, ed = relerr(dU, refU), relerr(dD, refD)
     print('lora_wgrad relerr', eu, ed)
     assert eu < 1e-3 and ed < 1e-3        # fp32 accumulation of exact bf16 products: only summation order differs
+
+
+def test_norm_passthrough_residual_gradient():
+    """group_norm_res / layer_norm_res: the second output is x for its residual use; dx = norm_bwd(dy) + d(residual)
+    is formed inside the backward kernel (t2v_gn_bwd_apply / t2v_layernorm_bwd `addend`)."""
+    import t2v_amd.functional as F
+    g = torch.Generator().manual_seed(11)
+    nd, rows, C, G = 2, 96, 320, 32
+    x = _bf(torch.randn(nd * rows, C, generator=g) + 0.3); gm = torch.randn(C, generator=g); bt = torch.randn(C, generator=g)
+    dy = _bf(torch.randn(nd * rows, C, generator=g)); dr = _bf(torch.randn(nd * rows, C, generator=g))
+    # GroupNorm(+SiLU)
+    xr = x.float().requires_grad_()
+    y3 = TF.silu(TF.group_norm(xr.view(nd, rows, C).permute(0, 2, 1), G, gm, bt, 1e-5)).permute(0, 2, 1).reshape(nd * rows, C)
+    (y3 * dy.float()).sum().backward(retain_graph=True); (xr * dr.float()).sum().backward()
+    xd = _dev(x)
+    y, xres = F.group_norm_res(xd, gm.cuda(), bt.cuda(), G, 1e-5, True, nd)
+    assert xres.data_ptr() == xd.data_ptr()
+    torch.autograd.backward([y, xres], [dy.cuda(), dr.cuda()])
+    assert relerr(y, y3) < TOL and relerr(xd.grad, xr.grad) < 3e-2
+    xd2 = _dev(x)                              # pass-through output unused: plain backward
+    y2, _ = F.group_norm_res(xd2, gm.cuda(), bt.cuda(), G, 1e-5, True, nd)
+    y2.backward(dy.cuda())
+    xr2 = x.float().requires_grad_()
+    y4 = TF.silu(TF.group_norm(xr2.view(nd, rows, C).permute(0, 2, 1), G, gm, bt, 1e-5)).permute(0, 2, 1).reshape(nd * rows, C)
+    y4.backward(dy.float())
+    assert relerr(xd2.grad, xr2.grad) < 3e-2
+    # LayerNorm
+    xr = x.float().requires_grad_()
+    yl = TF.layer_norm(xr, (C,), gm, bt, 1e-5)
+    (yl * dy.float()).sum().backward(retain_graph=True); (xr * dr.float()).sum().backward()
+    xd = _dev(x)
+    y, xres = F.layer_norm_res(xd, gm.cuda(), bt.cuda(), 1e-5)
+    torch.autograd.backward([y, xres], [dy.cuda(), dr.cuda()])
+    assert relerr(y, yl) < TOL and relerr(xd.grad, xr.grad) < 3e-2
+
+
+@pytest.mark.parametrize("nimg,H,W,KH,KW,C,r", [(2, 8, 8, 3, 3, 64, 16), (3, 5, 7, 3, 3, 40, 8), (2, 4, 48, 3, 1, 128, 16),
+                                               (1, 6, 6, 3, 3, 24, 32)])
+def test_lowrank_window_update(nimg, H, W, KH, KW, C, r):
+    """y[q,c] += s sum_tap sum_j t[p(q,tap), j] D[j, tap, c]  (backward-data of a LoRA down conv) against torch fp32."""
+    import ctypes as C_
+    import t2v_amd.native as nv
+    rows, taps = nimg * H * W, KH * KW
+    g = torch.Generator().manual_seed(rows + C + r)
+    y = _bf(torch.randn(rows, C, generator=g)); t = _bf(torch.randn(rows, r, generator=g))
+    D = _bf(torch.randn(r, taps, C, generator=g) * 0.3)
+    py, px = KH // 2, KW // 2
+    ti = t.float().view(nimg, H, W, r)
+    tp = torch.zeros(nimg, H + KH - 1, W + KW - 1, r); tp[:, py:py + H, px:px + W] = ti
+    ref = y.float().clone().view(nimg, H, W, C)
+    for ky in range(KH):
+        for kx in range(KW):
+            # p = q - (ky - py, kx - px)  ->  padded index (iy - ky + 2py, ix - kx + 2px)
+            sh = tp[:, 2 * py - ky: 2 * py - ky + H, 2 * px - kx: 2 * px - kx + W]
+            ref += 0.5 * sh @ D.float()[:, ky * KW + kx, :]
+    yd, td, Dd = y.cuda(), t.cuda(), D.cuda()
+    geom = nv.ConvGeom(C, H, W, H, W, KH, KW, 1, 1, py, px, 1, 0)
+    nv.call("t2v_lowrank_window_update", yd.data_ptr(), C, td.data_ptr(), r, Dd.data_ptr(), taps * C, C_.byref(geom), rows, C, r,
+            0.5, nv.stream())
+    assert relerr(yd, ref.view(rows, C)) < 1e-2

@@ -277,6 +277,78 @@ __global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict_
   }
 }
 
+// Windowed form: y[q, c] += scale * sum_tap sum_j t[p(q, tap), j] * D[j, tap, c] — the backward-data of a LoRA down CONV
+// (dx += dt (*) D^T) with the window applied to the rank-wide operand: p(q, tap) is the output position that reads input
+// position q under `tap` (stride-1 same-size window, zero outside the image).  Same lane mapping as above; one 8-byte
+// gathered load of t and two MFMAs per tap.
+template <int R, int TAPS>
+__global__ __launch_bounds__(256) void lowrank_window_kernel(bf16_t* __restrict__ y, long long ldy, const bf16_t* __restrict__ t,
+                                                              long long ldt, const bf16_t* __restrict__ D, long long ldd,
+                                                              T2VConvGeom g, long long M, int N, float scale, int rows_per_block) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 4 + w) * 32;
+  if (c0 >= N) return;
+  const int li = lane & 15, gq = lane >> 4;
+  constexpr int KS = (R + 15) / 16;
+  constexpr int UN = 2;
+  bf16x4 a[TAPS][KS][2];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 16 * ks + 4 * gq + j, col = c0 + 8 * (li >> 2) + 4 * m + (li & 3);
+          a[tp][ks][m][j] = (k < R && col < N) ? (short)D[(long long)k * ldd + (long long)tp * N + col] : (short)0;
+        }
+  const int ccol = c0 + 8 * gq;
+  const bool cok = ccol < N;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  const bf16x4 zero4 = {0, 0, 0, 0};
+  const unsigned hw = (unsigned)(g.Hv * g.Wv);
+  for (long long row0 = r0; row0 < r1; row0 += 16 * UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (row0 + 16 * u >= r1) break;                      // wave-uniform
+      const long long row = row0 + 16 * u + li;
+      const bool ok = row < r1;
+      const unsigned uq = (unsigned)(ok ? row : r0);
+      const int n = (int)(uq / hw);
+      const unsigned rem = uq - (unsigned)n * hw;
+      const int iy = (int)(rem / (unsigned)g.Wv), ix = (int)(rem - (unsigned)iy * (unsigned)g.Wv);
+      bf16x8 yv;
+      if (ok && cok) yv = *(const bf16x8*)(y + row * ldy + ccol);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int ky = tp / g.KW, kx = tp - ky * g.KW;
+        const int oy = iy - ky + g.py, ox = ix - kx + g.px;
+        const bool v = ok && (unsigned)oy < (unsigned)g.Ho && (unsigned)ox < (unsigned)g.Wo;
+        const long long src = ((long long)n * g.Ho + oy) * g.Wo + ox;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int k0 = 16 * ks + 4 * gq;
+          const bf16x4 tb = (v && k0 < R) ? *(const bf16x4*)(t + src * ldt + k0) : zero4;
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[tp][ks][0], tb, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[tp][ks][1], tb, acc1, 0, 0, 0);
+        }
+      }
+      if (ok && cok) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (short)f2bf(bf2f((unsigned short)yv[e]) + scale * acc0[e]);
+          o[4 + e] = (short)f2bf(bf2f((unsigned short)yv[4 + e]) + scale * acc1[e]);
+        }
+        *(bf16x8*)(y + row * ldy + ccol) = o;
+      }
+    }
+  }
+}
+
 // direct convolution for tiny channel counts: one thread per (output position, output channel)
 __global__ __launch_bounds__(256) void smallconv_kernel(const T2VSmallConv p) {
   const T2VConvGeom g = p.geom;
@@ -403,6 +475,35 @@ extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long lo
   else if (r == 64) T2V_LRU(64);
   else T2V_LRU(96);
 #undef T2V_LRU
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+extern "C" int t2v_lowrank_window_update(void* y, long long ldy, const void* t, long long ldt, const void* D, long long ldd,
+                                         const T2VConvGeom* geom, long long M, int N, int r, float scale, t2v_stream_t s) {
+  T2V_CHECK_ARG(y && t && D && geom && M > 0 && M < (1LL << 31) && N > 0 && N % 8 == 0 && ldy % 8 == 0 && ldt % 8 == 0,
+                "t2v_lowrank_window_update: bad args");
+  T2V_CHECK_ARG(r == 8 || r == 16 || r == 24 || r == 32, "t2v_lowrank_window_update: rank must be 8, 16, 24 or 32 (got %d)", r);
+  const T2VConvGeom g = *geom;
+  const int taps = g.KH * g.KW;
+  T2V_CHECK_ARG((taps == 3 || taps == 9) && g.sy == 1 && g.sx == 1 && g.tdiv == 1 && g.up == 0 && g.Hv == g.Ho && g.Wv == g.Wo &&
+                    g.Hv > 0 && g.Wv > 0 && M % ((long long)g.Hv * g.Wv) == 0,
+                "t2v_lowrank_window_update: needs a stride-1 same-size window of 3 or 9 taps over whole images");
+  T2V_CHECK_ARG(ldd >= (long long)taps * N, "t2v_lowrank_window_update: D leading dimension too small");
+  const int ncb = (N + 127) / 128;
+  long long want_blocks = 2048;
+  int rpb = (int)std::max<long long>(32, ((M * ncb + want_blocks - 1) / want_blocks + 31) / 32 * 32);
+  dim3 grid(ncb, (unsigned)((M + rpb - 1) / rpb));
+#define T2V_LRW(RR, TT)                                                                                                   \
+  hipLaunchKernelGGL((lowrank_window_kernel<RR, TT>), grid, dim3(256), 0, (hipStream_t)s, (bf16_t*)y, ldy, (const bf16_t*)t, \
+                     ldt, (const bf16_t*)D, ldd, g, M, N, scale, rpb)
+#define T2V_LRW_R(TT)          \
+  if (r == 8) T2V_LRW(8, TT);  \
+  else if (r == 16) T2V_LRW(16, TT); \
+  else if (r == 24) T2V_LRW(24, TT); \
+  else T2V_LRW(32, TT)
+  if (taps == 3) { T2V_LRW_R(3); } else { T2V_LRW_R(9); }
+#undef T2V_LRW_R
+#undef T2V_LRW
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

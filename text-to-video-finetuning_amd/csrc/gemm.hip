@@ -284,14 +284,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
   }
   const bf16_t* brow[NCB];
   bool bok[NCB];
+  unsigned b2mask = 0;                                   // rows of the second weight block (valid only inside its K window)
+  const int wlo = p.b2_klen > 0 ? p.b2_k0 : 0, whi = p.b2_klen > 0 ? p.b2_k0 + p.b2_klen : 0x7fffffff;
 #pragma unroll
   for (int i = 0; i < NCB; ++i) {
     int n = n0 + (tid >> 3) + RPP * i;
     bok[i] = n < N;
-    if (p.n_split > 0 && n >= p.n_split)
-      brow[i] = (const bf16_t*)p.B2 + (long long)(bok[i] ? n - p.n_split : 0) * p.ldb2;
-    else
+    if (p.n_split > 0 && n >= p.n_split) {
+      brow[i] = (const bf16_t*)p.B2 + (long long)(bok[i] ? n - p.n_split : 0) * p.ldb2 - wlo;
+      b2mask |= 1u << i;
+    } else {
       brow[i] = B + (long long)(bok[i] ? n : 0) * p.ldb;
+    }
   }
 
   auto issue = [&](int k0, int stage) {
@@ -331,9 +335,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
                                          (__attribute__((address_space(3))) void*)(sA + (tid + NT * i) * 16), 16, 0, 0);
       }
     }
+    const bool win = kidx >= wlo && kidx < whi;
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
-      const bf16_t* src = (bok[i] && kok) ? brow[i] + kidx : zp;
+      const bf16_t* src = (bok[i] && kok && (win || !((b2mask >> i) & 1u))) ? brow[i] + kidx : zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sB + (tid + NT * i) * 16), 16, 0, 0);
     }
@@ -460,15 +465,19 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
   const bf16_t* brow[NCB];
   bool bok[NCB];
   int btap = 0, bc = 0;
+  unsigned b2mask = 0;
+  const int wlo = p.b2_klen > 0 ? p.b2_k0 : 0, whi = p.b2_klen > 0 ? p.b2_k0 + p.b2_klen : 0x7fffffff;
   if constexpr (!BT) {
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       int n = n0 + (tid >> 3) + 32 * i;
       bok[i] = n < N;
-      if (p.n_split > 0 && n >= p.n_split)
-        brow[i] = (const bf16_t*)p.B2 + (long long)(bok[i] ? n - p.n_split : 0) * p.ldb2;
-      else
+      if (p.n_split > 0 && n >= p.n_split) {
+        brow[i] = (const bf16_t*)p.B2 + (long long)(bok[i] ? n - p.n_split : 0) * p.ldb2 - wlo;
+        b2mask |= 1u << i;
+      } else {
         brow[i] = B + (long long)(bok[i] ? n : 0) * p.ldb;
+      }
     }
   } else if (p.b_conv) {
     int nn = n0 + (tid % (BN / 8)) * 8;
@@ -510,8 +519,10 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
     if constexpr (!BT) {
       const int kidx = k0 + (tid & 7) * 8;
       const bool kok = kidx < kend;
+      const bool win = kidx >= wlo && kidx < whi;
 #pragma unroll
-      for (int i = 0; i < NCB; ++i) rb[i] = (bok[i] && kok) ? *(const bf16x8*)(brow[i] + kidx) : zero8;
+      for (int i = 0; i < NCB; ++i)
+        rb[i] = (bok[i] && kok && (win || !((b2mask >> i) & 1u))) ? *(const bf16x8*)(brow[i] + kidx) : zero8;
     } else {
       constexpr int CPR = BN / 8, RPP = 256 / CPR;
       const int nn = n0 + (tid % CPR) * 8;
@@ -960,6 +971,9 @@ int check_gemm(const T2VGemm& p) {
   if (p.a_trans) T2V_CHECK_ARG(p.M % 8 == 0, "t2v_gemm: a_trans needs M%%8==0 (M=%d)", p.M);
   if (p.b_trans) T2V_CHECK_ARG(p.N % 8 == 0, "t2v_gemm: b_trans needs N%%8==0 (N=%d)", p.N);
   if (p.rowbias) T2V_CHECK_ARG(p.rows_per_rb > 0, "t2v_gemm: rows_per_rb must be > 0");
+  T2V_CHECK_ARG(p.b2_klen <= 0 || (p.n_split > 0 && p.b2_k0 >= 0 && p.b2_k0 % 8 == 0 && p.b2_klen % 8 == 0 &&
+                                   p.b2_k0 + p.b2_klen <= p.K),
+                "t2v_gemm: bad second-block K window [%d, +%d)", p.b2_k0, p.b2_klen);
   if (p.n_split > 0) {
     T2V_CHECK_ARG(!p.b_trans && p.B2 && p.D2 && p.n_split % 8 == 0 && p.n_split < p.N && p.ldb2 % 8 == 0 && p.ldd2 % 8 == 0 &&
                       p.out_mode == T2V_OUT_BF16 && p.batch <= 1 && p.split_k <= 1,

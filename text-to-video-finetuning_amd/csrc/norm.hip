@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                         bf16_t* __restrict__ y, long long ldy, int rows_per_domain, int C, int G,
                                                         const float* __restrict__ sums, const float* __restrict__ bsums,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, int silu, float drop_p, unsigned long long drop_seed) {
+                                                        float eps, int silu, float drop_p, unsigned long long drop_seed,
+                                                        const bf16_t* __restrict__ addend, long long ldadd) {
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -234,13 +235,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     }
     const long long base = (long long)d * rows_per_domain;
     for (int r = rbeg + rl; r < rend; r += UN * rpp) {
-      bf16x8 xv[UN], gv[UN];
+      bf16x8 xv[UN], gv[UN], av[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int rr = r + u * rpp;
         if (rr < rend) {
           xv[u] = *(const bf16x8*)(x + (base + rr) * ldx + cc * 8);
           if (BWD) gv[u] = *(const bf16x8*)(dy + (base + rr) * lddy + cc * 8);
+          if (BWD && addend) av[u] = *(const bf16x8*)(addend + (base + rr) * ldadd + cc * 8);
         }
       }
 #pragma unroll
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
               dz *= sg * (1.f + zz * (1.f - sg));
             }
             out = rs[e] * (dz * gm[e] - b1[e] - xh * b2[e]);
+            if (addend) out += bf2f((unsigned short)av[u][e]);      // gradient of a pass-through (residual) use of x
           }
           ov[e] = (short)f2bf(out);
         }
@@ -335,7 +338,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       const bf16_t* __restrict__ dy, long long lddy,
                                                       bf16_t* __restrict__ dx, long long lddx, int rows, int C,
                                                       const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      const bf16_t* __restrict__ addend, long long ldadd) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = C >> 3;
   float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
@@ -378,8 +382,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       int ch = lane + 64 * i;
       if (ch < nch) {
         bf16x8 ov;
+        if (addend) {                                     // + gradient of a pass-through (residual) use of x
+          const bf16x8 av = *(const bf16x8*)(addend + row * ldadd + ch * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2));
+          for (int e = 0; e < 8; ++e)
+            ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2) + bf2f((unsigned short)av[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2));
+        }
         *(bf16x8*)(dx + row * lddx + ch * 8) = ov;
       }
     }
@@ -451,7 +462,8 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
   T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_apply: bad domain grid");
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
   hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
-                     0, (bf16_t*)y, ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed);
+                     0, (bf16_t*)y, ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed,
+                     (const bf16_t*)nullptr, 0LL);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -477,15 +489,16 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
 extern "C" int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
                                 int ndomains, int rows_per_domain, int C, int G, const float* sums, const float* bsums,
                                 const float* gamma, const float* beta, float eps, int silu, float drop_p,
-                                unsigned long long drop_seed, t2v_stream_t stream) {
+                                unsigned long long drop_seed, const void* addend, long long ldadd, t2v_stream_t stream) {
   if (int e = gn_check("t2v_gn_bwd_apply", C, G, ldx)) return e;
+  T2V_CHECK_ARG(!addend || ldadd % 8 == 0, "t2v_gn_bwd_apply: addend leading dimension must be a multiple of 8");
   T2V_CHECK_ARG(x && dy && dx && sums && bsums && gamma && beta && lddy % 8 == 0 && lddx % 8 == 0,
                 "t2v_gn_bwd_apply: bad args");
   T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_bwd_apply: bad domain grid");
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
   hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,
-                     silu, drop_p, drop_seed);
+                     silu, drop_p, drop_seed, (const bf16_t*)addend, ldadd);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -503,14 +516,15 @@ extern "C" int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long lon
 
 extern "C" int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
                                  int rows, int C, const float* gamma, const float* stats, float* dgamma, float* dbeta,
-                                 t2v_stream_t stream) {
+                                 const void* addend, long long ldadd, t2v_stream_t stream) {
+  T2V_CHECK_ARG(!addend || ldadd % 8 == 0, "t2v_layernorm_bwd: addend leading dimension must be a multiple of 8");
   T2V_CHECK_ARG(x && dy && dx && gamma && stats && rows > 0, "t2v_layernorm_bwd: bad args");
   T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
                 "t2v_layernorm_bwd: need C%%8==0, C<=2048 (C=%d)", C);
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_layernorm_bwd: dgamma/dbeta must both be set or NULL");
   int grid = min((rows + 3) / 4, dgamma ? 1024 : 16384);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, dgamma, dbeta);
+                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, dgamma, dbeta, (const bf16_t*)addend, ldadd);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

@@ -157,7 +157,7 @@ def launch_gemm_pair(kw_a, kw_b):
 def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0, b_conv=0, geom=None, out_mode=0,
                 bias=None, rowbias=None, ldrb=0, rows_per_rb=0, R=None, ldr=0, alpha=1.0, beta=1.0, act=0, batch=1,
                 strideA=0, strideB=0, strideD=0, strideR=0, split_k=1, drop_p=0.0, drop_seed=0, B2=None, ldb2=0, n_split=0,
-                D2=None, ldd2=0, b_tapflip=0):
+                D2=None, ldd2=0, b_tapflip=0, b2_k0=0, b2_klen=0):
     g = Gemm = nv.Gemm()
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.a_mode, g.a_trans = A, lda, a_mode, a_trans
@@ -173,6 +173,7 @@ def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0
     g.split_k = split_k
     g.drop_p, g.drop_seed = drop_p, drop_seed
     g.B2, g.ldb2, g.n_split, g.D2, g.ldd2, g.b_tapflip = B2, ldb2, n_split, D2, ldd2, b_tapflip
+    g.b2_k0, g.b2_klen = b2_k0, b2_klen
     if out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
         ws = _gemm_workspace()
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -399,6 +400,18 @@ class _LoraLayer(torch.autograd.Function):
                         D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p,
                         D2=dt.data_ptr(), ldd2=e.rp)
             _lowrank_update(dx, dt, e.down_w16, M, cin_p, e.rp, scale)           # dx += s dt D
+        elif need_dx and e.rp <= 32 and _wgrad_window_ok(cfg.fwd_geom(cin_p), M) and cfg.taps() in (3, 9):
+            # stride-1 same-size conv: dt = dy U rides in the backward-data launch (rp extra output columns whose weights
+            # exist only at the tap that gathers the row itself), then dx += s dt (*) D^T as a windowed rank update
+            wb = prepared_weight(w_base, "bwd")
+            bg = cfg.bwd_geom(npad)
+            dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+            launch_gemm(M=M, N=cin_p + e.rp, K=wb.shape[1], A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
+                        D=dx.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=bg, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16),
+                        n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp, b2_k0=(bg.py * bg.KW + bg.px) * npad, b2_klen=npad)
+            fg = cfg.fwd_geom(cin_p)
+            nv.call("t2v_lowrank_window_update", dx.data_ptr(), cin_p, dt.data_ptr(), e.rp, e.down_w16.data_ptr(),
+                    cfg.taps() * cin_p, C.byref(fg), M, cin_p, e.rp, scale, nv.stream())
         else:
             launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16),
                         D=dt.data_ptr(), ldd=e.rp)
@@ -593,7 +606,7 @@ def _gn_workspace(ndomains, G, device):
 
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, G, eps, silu, ndomains, drop_p, drop_seed):
+    def forward(ctx, x, gamma, beta, G, eps, silu, ndomains, drop_p, drop_seed, passthrough=False):
         x = _mat(x, "x")
         rows, Cc = x.shape
         rpd = rows // ndomains
@@ -607,13 +620,19 @@ class _GroupNorm(torch.autograd.Function):
                 g32.data_ptr(), b32.data_ptr(), eps, int(silu), drop_p, drop_seed, s)
         ctx.args = (G, eps, int(silu), ndomains, rpd, drop_p, drop_seed)
         ctx.save_for_backward(x, gamma, beta, sums)
+        if passthrough:          # second output: x itself, for the residual use — its gradient is summed inside bwd_apply
+            return y, x.detach()
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, sums = ctx.saved_tensors
         G, eps, silu, ndomains, rpd, drop_p, drop_seed = ctx.args
+        if dy is None:
+            return (dres,) + (None,) * 9
         dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        if dres is not None:
+            dres = _mat(dres if dres.stride(1) == 1 else dres.contiguous(), "dres")
         rows, Cc = x.shape
         g32, b32 = _f32(gamma), _f32(beta)
         s = nv.stream()
@@ -627,19 +646,26 @@ class _GroupNorm(torch.autograd.Function):
                 nv.ptr(dbt), s)
         dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
         nv.call("t2v_gn_bwd_apply", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, ndomains, rpd, Cc, G,
-                sums.data_ptr(), bsums.data_ptr(), g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, s)
+                sums.data_ptr(), bsums.data_ptr(), g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed,
+                nv.ptr(dres), _ld(dres) if dres is not None else 0, s)
         return (dx, dgm.to(gamma.dtype) if want_pg else None, dbt.to(beta.dtype) if want_pg else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def group_norm(x, gamma, beta, G, eps, silu, ndomains, drop_p=0.0, drop_seed=0):
     return _GroupNorm.apply(x, gamma, beta, G, float(eps), bool(silu), int(ndomains), float(drop_p), int(drop_seed))
 
 
+def group_norm_res(x, gamma, beta, G, eps, silu, ndomains, drop_p=0.0, drop_seed=0):
+    """(group_norm(x), x_res): use `x_res` wherever x itself is consumed again (the residual around the normalised branch);
+    the two gradients are then summed inside the backward-apply kernel instead of by a separate add."""
+    return _GroupNorm.apply(x, gamma, beta, G, float(eps), bool(silu), int(ndomains), float(drop_p), int(drop_seed), True)
+
+
 # --------------------------------------------------------------------------- LayerNorm
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, passthrough=False):
         x = _mat(x, "x")
         rows, Cc = x.shape
         y = torch.empty(rows, Cc, dtype=BF16, device=x.device)
@@ -647,24 +673,36 @@ class _LayerNorm(torch.autograd.Function):
         nv.call("t2v_layernorm_fwd", x.data_ptr(), _ld(x), y.data_ptr(), Cc, rows, Cc, _f32(gamma).data_ptr(),
                 _f32(beta).data_ptr(), eps, stats.data_ptr(), nv.stream())
         ctx.save_for_backward(x, gamma, beta, stats)
+        if passthrough:
+            return y, x.detach()
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, stats = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None
         dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        if dres is not None:
+            dres = _mat(dres if dres.stride(1) == 1 else dres.contiguous(), "dres")
         rows, Cc = x.shape
         want_pg = gamma.requires_grad or beta.requires_grad
         dgm = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         dbt = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
         nv.call("t2v_layernorm_bwd", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, rows, Cc,
-                _f32(gamma).data_ptr(), stats.data_ptr(), nv.ptr(dgm), nv.ptr(dbt), nv.stream())
-        return dx, dgm.to(gamma.dtype) if want_pg else None, dbt.to(beta.dtype) if want_pg else None, None
+                _f32(gamma).data_ptr(), stats.data_ptr(), nv.ptr(dgm), nv.ptr(dbt), nv.ptr(dres),
+                _ld(dres) if dres is not None else 0, nv.stream())
+        return dx, dgm.to(gamma.dtype) if want_pg else None, dbt.to(beta.dtype) if want_pg else None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+def layer_norm_res(x, gamma, beta, eps=1e-5):
+    """(layer_norm(x), x_res) — see group_norm_res."""
+    return _LayerNorm.apply(x, gamma, beta, float(eps), True)
 
 
 # --------------------------------------------------------------------------- attention core

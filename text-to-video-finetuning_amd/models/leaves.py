@@ -173,16 +173,17 @@ class ResnetBlock2D(nn.Module):
         if self.output_scale_factor != 1.0:
             raise RuntimeError("t2v_amd: output_scale_factor != 1 is not used by the reference configs")
         cfg3 = ConvCfg.conv2d(x.n, x.h, x.w, 3, 1, 1)
-        a = F.group_norm(x.m, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, True, x.n)
+        # xr: x for its second (shortcut / residual) use — its gradient is summed inside norm1's backward kernel
+        a, xr = F.group_norm_res(x.m, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, True, x.n)
         rb = None
         if temb is not None and self.time_emb_proj is not None:
             rb = run_layer(self.time_emb_proj, temb.act)          # [B, Cout]; broadcast over the B's F*h*w rows
         h = run_layer(self.conv1, a, cfg3, rowbias=rb)
         a2 = F.group_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, x.n,
                           _drop_p(self.dropout), _next_seed() if _drop_p(self.dropout) > 0 else 0)
-        sc = x.m
+        sc = xr
         if self.conv_shortcut is not None:
-            sc = run_layer(self.conv_shortcut, x.m, ConvCfg.conv2d(x.n, x.h, x.w, 1, 1, 0))
+            sc = run_layer(self.conv_shortcut, xr, ConvCfg.conv2d(x.n, x.h, x.w, 1, 1, 0))
         out = run_layer(self.conv2, a2, cfg3, residual=sc)
         return Tok(out, x.n, x.h, x.w)
 
@@ -207,13 +208,16 @@ class TemporalConvLayer(nn.Module):
     def forward(self, x, num_frames=1):
         B = x.n // num_frames
         cfg = ConvCfg.conv3d_t(B, num_frames, x.h * x.w)
-        cur = x.m
+        cur, xr = x.m, None
         seqs = (self.conv1, self.conv2, self.conv3, self.conv4)
         for i, seq in enumerate(seqs):
             gn, conv = seq[0], seq[-1]
             p = max((_drop_p(mm) for mm in seq), default=0.0)
-            a = F.group_norm(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
-            cur = run_layer(conv, a, cfg, residual=x.m if i == 3 else None)
+            if i == 0:       # xr: the identity branch's use of x (gradient summed inside the first norm's backward kernel)
+                a, xr = F.group_norm_res(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
+            else:
+                a = F.group_norm(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
+            cur = run_layer(conv, a, cfg, residual=xr if i == 3 else None)
         return Tok(cur, x.n, x.h, x.w)
 
 
@@ -298,9 +302,13 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, t, qlay, ctx=None, klay=None):
-        t = self.attn1(F.layer_norm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps), qlay, residual=t)
-        t = self.attn2(F.layer_norm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps), qlay, ctx, klay, residual=t)
-        return self.ff(F.layer_norm(t, self.norm3.weight, self.norm3.bias, self.norm3.eps), residual=t)
+        # (normalised, pass-through) pairs: the residual's gradient is summed inside each LayerNorm's backward kernel
+        n, r = F.layer_norm_res(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        t = self.attn1(n, qlay, residual=r)
+        n, r = F.layer_norm_res(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        t = self.attn2(n, qlay, ctx, klay, residual=r)
+        n, r = F.layer_norm_res(t, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self.ff(n, residual=r)
 
 
 class TextCtx:
@@ -328,14 +336,14 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, encoder_hidden_states=None, num_frames=1, **_):
         hw = x.h * x.w
-        a = F.group_norm(x.m, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, False, x.n)
+        a, xr = F.group_norm_res(x.m, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, False, x.n)
         t = run_layer(self.proj_in, a)
         qlay = SeqLayout(x.n, hw, hw, 0, 1, 1)
         ctx = encoder_hidden_states
         klay = SeqLayout(x.n, ctx.S, ctx.S, 0, 1, x.n // ctx.B)
         for blk in self.transformer_blocks:
             t = blk(t, qlay, ctx.m, klay)
-        out = run_layer(self.proj_out, t, residual=x.m)
+        out = run_layer(self.proj_out, t, residual=xr)
         return _Out(sample=Tok(out, x.n, x.h, x.w))
 
 
@@ -356,13 +364,13 @@ class TransformerTemporalModel(nn.Module):
     def forward(self, x, encoder_hidden_states=None, num_frames=1, **_):
         hw = x.h * x.w
         B = x.n // num_frames
-        a = F.group_norm(x.m, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, False, B)
+        a, xr = F.group_norm_res(x.m, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, False, B)
         t = run_layer(self.proj_in, a)
         # rows are (b, f, pixel): a sequence = the F rows of one pixel, stride hw rows — no permute copies
         qlay = SeqLayout(B * hw, num_frames, num_frames * hw, 1, hw, hw)
         for blk in self.transformer_blocks:
             t = blk(t, qlay)
-        out = run_layer(self.proj_out, t, residual=x.m)
+        out = run_layer(self.proj_out, t, residual=xr)
         return _Out(sample=Tok(out, x.n, x.h, x.w))
 
 

@@ -47,7 +47,7 @@ class Gemm(C.Structure):
         ("split_k", c_int),
         ("drop_p", c_float), ("drop_seed", c_ull),
         ("B2", c_void_p), ("ldb2", c_ll), ("n_split", c_int), ("D2", c_void_p), ("ldd2", c_ll),
-        ("b_tapflip", c_int),
+        ("b_tapflip", c_int), ("b2_k0", c_int), ("b2_klen", c_int),
         ("workspace", c_void_p), ("workspace_bytes", C.c_size_t), ("ws_split", c_int),
     ]
 
@@ -93,17 +93,19 @@ SYMBOLS = {
     "t2v_gn_bwd_stats": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                           c_float, c_int, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "t2v_gn_bwd_apply": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_float, c_int, c_float, c_ull, c_void_p], c_int),
+                          c_void_p, c_void_p, c_float, c_int, c_float, c_ull, c_void_p, c_ll, c_void_p], c_int),
     "t2v_layernorm_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p],
                           c_int),
     "t2v_layernorm_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                           c_void_p, c_void_p], c_int),
+                           c_void_p, c_void_p, c_ll, c_void_p], c_int),
     "t2v_attn_fwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_attn_bwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_softmax_rows": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_void_p], c_int),
     "t2v_dropout_mask": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_lowrank_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_void_p], c_int),
     "t2v_lora_wgrad": ([C.POINTER(LoraWgrad), c_void_p], c_int),
+    "t2v_lowrank_window_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, C.POINTER(ConvGeom), c_ll, c_int, c_int,
+                                   c_float, c_void_p], c_int),
     "t2v_geglu_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_geglu_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_silu_fwd": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),
