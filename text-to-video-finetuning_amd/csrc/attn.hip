@@ -4,7 +4,9 @@
 // sequence in 32-row tiles; everything stays in registers (flash-style online softmax), MFMA 32x32x16 bf16:
 //   fwd : S^T = K Q^T (lane = query -> row max/sum are lane-local + one cross-half shuffle),
 //         O^T += V^T P^T  where P^T is fed straight from the S^T accumulator registers as the B operand and
-//         V^T fragments come from a wave-private LDS tile through ds_read_b64_tr_b16 (hardware transpose);
+//         V^T fragments come from a wave-private LDS tile through ds_read_b64_tr_b16 (hardware transpose) — each tile
+//         row is loaded ONCE, as MFMA operand fragments, and the same registers are written to the LDS tile; the next
+//         tile's rows are in flight while the current tile is processed;
 //         the MFMA k-slot <-> key permutation implied by the accumulator layout is applied to both operands.
 //   dQ  : same layout, dS^T from registers, K^T via transpose reads.        (also produces delta = rowsum(dO*O))
 //   dKdV: S = Q K^T (lane = key), dV^T += dO^T P, dK^T += Q^T dS with Q^T/dO^T via transpose reads.
@@ -14,7 +16,8 @@
 
 namespace {
 
-constexpr int LDT = 96;  // LDS tile row stride (elements): 64 + 32 pad keeps the transpose reads conflict-free
+constexpr int LDT = 104;  // LDS tile row stride (elements): 64 + 40 pad — row-per-lane 16-byte writes and the transposed reads
+                          // both spread over the banks (52-dword row pitch)
 
 __device__ __forceinline__ long long op_off(const T2VAttnOperand& o, int b, int h) {
   return (long long)(b / o.bdiv) * o.bstride_hi + (long long)(b % o.bdiv) * o.bstride_lo + h * 64;
@@ -25,14 +28,17 @@ __device__ __forceinline__ bf16x8 ldg8(const bf16_t* p, bool ok) {
   const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   return ok ? *(const bf16x8*)p : z;
 }
-// stage a [32 rows][64] tile (rows r0.. of a strided sequence) into wave-private LDS
-__device__ __forceinline__ void stage_tile(bf16_t* s, const bf16_t* base, long long ss, int r0, int rmax, int lane) {
+// the lane's four 16-byte pieces of tile row (r0 + lane&31): pieces 2*kd + (lane>>5) — exactly the MFMA operand fragments
+// of X (rows = tile rows); the same registers are written to LDS for the transposed reads (no second global load)
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[4], const bf16_t* base, long long ss, int r0, int rmax, int lane) {
+  const int row = r0 + (lane & 31), hi = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = lane + 64 * i, rr = c >> 3, dch = c & 7;
-    bf16x8 v = ldg8(base + (long long)(r0 + rr) * ss + dch * 8, r0 + rr < rmax);
-    *(bf16x8*)(s + rr * LDT + dch * 8) = v;
-  }
+  for (int kd = 0; kd < 4; ++kd) f[kd] = ldg8(base + (long long)row * ss + 16 * kd + 8 * hi, row < rmax);
+}
+__device__ __forceinline__ void frags_to_lds(bf16_t* s, const bf16x8 (&f)[4], int lane) {
+  const int rr = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) *(bf16x8*)(s + rr * LDT + 16 * kd + 8 * hi) = f[kd];
 }
 // A-operand fragment of X^T (rows = 32 feature columns [32*fm, 32*fm+32), k = the 16 tile rows of k-step kk,
 // permuted exactly like the accumulator-register order) from an LDS tile X[row][feature]
@@ -84,17 +90,26 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const T2VAttn p) {
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+  bf16x8 kn[4], vn[4];                                   // next tile's K / V rows, in flight during this tile's math
+  load_row_frags(kn, K, p.k.sstride, 0, Sk, lane);
+  load_row_frags(vn, V, p.v.sstride, 0, Sk, lane);
   for (int kt = 0; kt < Sk; kt += 32) {
-    const int key = kt + l31;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      kf[kd] = kn[kd];
+      vf[kd] = vn[kd];
+    }
+    if (kt + 32 < Sk) {
+      load_row_frags(kn, K, p.k.sstride, kt + 32, Sk, lane);
+      load_row_frags(vn, V, p.v.sstride, kt + 32, Sk, lane);
+    }
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int kd = 0; kd < 4; ++kd) {
-      bf16x8 kf = ldg8(K + (long long)key * p.k.sstride + 16 * kd + 8 * hi, key < Sk);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
-    }
-    stage_tile(sV, V, p.v.sstride, kt, Sk, lane);
+    for (int kd = 0; kd < 4; ++kd) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kd], qf[kd], s, 0, 0, 0);
+    frags_to_lds(sV, vf, lane);
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -164,19 +179,29 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
   f32x16 a0, a1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
+  bf16x8 kn[4], vn[4];
+  load_row_frags(kn, K, p.k.sstride, 0, Sk, lane);
+  load_row_frags(vn, V, p.v.sstride, 0, Sk, lane);
   for (int kt = 0; kt < Sk; kt += 32) {
-    const int key = kt + l31;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      kf[kd] = kn[kd];
+      vf[kd] = vn[kd];
+    }
+    if (kt + 32 < Sk) {
+      load_row_frags(kn, K, p.k.sstride, kt + 32, Sk, lane);
+      load_row_frags(vn, V, p.v.sstride, kt + 32, Sk, lane);
+    }
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
     for (int kd = 0; kd < 4; ++kd) {
-      bf16x8 kf = ldg8(K + (long long)key * p.k.sstride + 16 * kd + 8 * hi, key < Sk);
-      bf16x8 vf = ldg8(V + (long long)key * p.v.sstride + 16 * kd + 8 * hi, key < Sk);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kd], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kd], qf[kd], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kd], dof[kd], dp, 0, 0, 0);
     }
-    stage_tile(sK, K, p.k.sstride, kt, Sk, lane);
+    frags_to_lds(sK, kf, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float pv = (kt + crow(r, hi) < Sk) ? __expf(s[r] * p.scale - lse) : 0.f;
@@ -218,20 +243,30 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
   f32x16 k0, k1, v0, v1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) k0[r] = k1[r] = v0[r] = v1[r] = 0.f;
+  bf16x8 qn[4], dn[4];
+  load_row_frags(qn, Q, p.q.sstride, 0, Sq, lane);
+  load_row_frags(dn, dO, p.d_o.sstride, 0, Sq, lane);
   for (int qt = 0; qt < Sq; qt += 32) {
-    const int qrow = qt + l31;
+    bf16x8 qa[4], da[4];
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      qa[kd] = qn[kd];
+      da[kd] = dn[kd];
+    }
+    if (qt + 32 < Sq) {
+      load_row_frags(qn, Q, p.q.sstride, qt + 32, Sq, lane);
+      load_row_frags(dn, dO, p.d_o.sstride, qt + 32, Sq, lane);
+    }
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
     for (int kd = 0; kd < 4; ++kd) {
-      bf16x8 qa = ldg8(Q + (long long)qrow * p.q.sstride + 16 * kd + 8 * hi, qrow < Sq);
-      bf16x8 da = ldg8(dO + (long long)qrow * p.d_o.sstride + 16 * kd + 8 * hi, qrow < Sq);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kd], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kd], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kd], kf[kd], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[kd], vf[kd], dp, 0, 0, 0);
     }
-    stage_tile(sQ, Q, p.q.sstride, qt, Sq, lane);
-    stage_tile(sD, dO, p.d_o.sstride, qt, Sq, lane);
+    frags_to_lds(sQ, qa, lane);
+    frags_to_lds(sD, da, lane);
     f32x16 pr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -868,16 +868,24 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   (void)hipEventCreate(&e1);
   DmaCfg best = heuristic_cfg(p);
   float best_ms = 1e30f;
+  (void)hipDeviceSynchronize();      // nothing else in flight (side-stream launches of earlier layers would skew the timings)
+  constexpr int ROUNDS = 3, REPS = 4;
   for (const DmaCfg& c : cand) {
     if (launch_dma_cfg(q, c, s) != T2V_OK) continue;      // warm (also sets the LDS attribute)
-    (void)hipEventRecord(e0, s);
-    launch_dma_cfg(q, c, s);
-    launch_dma_cfg(q, c, s);
-    (void)hipEventRecord(e1, s);
-    if (hipEventSynchronize(e1) != hipSuccess) continue;
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    if (tune_log > 1) fprintf(stderr, "[t2v tune]   M=%d N=%d K=%d conv=%d tile %d stages %d split %d: %.1f us\n", p.M, p.N, p.K, p.a_mode, c.tile, c.stages, c.split, ms * 500.f);
+    float ms = 1e30f;
+    bool ok = true;
+    for (int rd = 0; rd < ROUNDS && ok; ++rd) {           // best of ROUNDS x (REPS back-to-back launches)
+      (void)hipEventRecord(e0, s);
+      for (int i = 0; i < REPS; ++i) launch_dma_cfg(q, c, s);
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) { ok = false; break; }
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, e0, e1);
+      ms = t < ms ? t : ms;
+    }
+    if (!ok) continue;
+    ms /= REPS;
+    if (tune_log > 1) fprintf(stderr, "[t2v tune]   M=%d N=%d K=%d conv=%d tile %d stages %d split %d: %.1f us\n", p.M, p.N, p.K, p.a_mode, c.tile, c.stages, c.split, ms * 1000.f);
     if (ms < best_ms) { best_ms = ms; best = c; }
   }
   (void)hipEventDestroy(e0);
@@ -889,7 +897,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   }
   if (tune_log)
     fprintf(stderr, "[t2v tune] M=%d N=%d K=%d conv=%d -> tile %d stages %d split %d (%.1f us)\n", p.M, p.N, p.K, p.a_mode, best.tile,
-            best.stages, best.split, best_ms * 500.f);
+            best.stages, best.split, best_ms * 1000.f);
   return best;
 }
 
