@@ -293,6 +293,181 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short self-attention sequences (S = Sq = Sk <= 16, S | 32: the temporal attention over F frames): P = 32/S sequences
+// of consecutive batches are packed into ONE 32-row tile — lane&31 = packed row = (sequence lane/S, position lane%S) —
+// and the 32x32 score tile is block-diagonal-masked.  Every lane does useful work (a lone S=16 sequence would idle half
+// the wave) and the whole problem of a tile is resident in one wave: forward is one pass, backward produces dQ, dK and dV
+// in ONE kernel from a single load of Q, K, V, dO (the two score orientations cost 8 extra MFMAs, nothing is re-read).
+struct PackedRow {
+  int b, pos, sub;
+  bool ok;
+};
+__device__ __forceinline__ PackedRow packed_row(const T2VAttn& p, int S, int P, int l31) {
+  PackedRow r;
+  r.sub = l31 / S;
+  r.pos = l31 - r.sub * S;
+  r.b = blockIdx.x * P + r.sub;
+  r.ok = r.b < p.nbatch;
+  if (!r.ok) r.b = 0;
+  return r;
+}
+__device__ __forceinline__ const bf16_t* prow(const T2VAttnOperand& o, const PackedRow& r, int h) {
+  return (const bf16_t*)o.ptr + op_off(o, r.b, h) + (long long)r.pos * o.sstride;
+}
+__device__ __forceinline__ void load_frags(bf16x8 (&f)[4], const bf16_t* row, bool ok, int hi) {
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) f[kd] = ldg8(row + 16 * kd + 8 * hi, ok);
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_packed_kernel(const T2VAttn p, int S, int P) {
+  __shared__ __attribute__((aligned(16))) bf16_t sV[32 * LDT];
+  const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31, h = blockIdx.y;
+  const PackedRow R = packed_row(p, S, P, l31);
+  bf16x8 qf[4], kf[4], vf[4];
+  load_frags(qf, prow(p.q, R, h), R.ok, hi);
+  load_frags(kf, prow(p.k, R, h), R.ok, hi);
+  load_frags(vf, prow(p.v, R, h), R.ok, hi);
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kd], qf[kd], s, 0, 0, 0);
+  frags_to_lds(sV, vf, lane);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float sv = (R.ok && crow(r, hi) / S == R.sub) ? s[r] * p.scale : -INFINITY;
+    s[r] = sv;
+    mx = fmaxf(mx, sv);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float m = R.ok ? mx : 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pv = __expf(s[r] - m);
+    s[r] = pv;
+    l += pv;
+  }
+  l += __shfl_xor(l, 32);
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const bf16x8 pb = pack8(s, kk);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sV, 0, kk, lane), pb, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sV, 1, kk, lane), pb, o1, 0, 0, 0);
+  }
+  if (R.ok) {
+    store_rowT((bf16_t*)prow(p.o, R, h), 0, 0, o0, o1, 1.f / l, hi);
+    if (hi == 0 && p.lse) p.lse[((long long)R.b * p.heads + h) * S + R.pos] = m + __logf(l);
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_packed_kernel(const T2VAttn p, int S, int P) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[32 * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_t sD[32 * LDT];
+  __shared__ float sL[32], sDl[32];
+  const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31, h = blockIdx.y;
+  const PackedRow R = packed_row(p, S, P, l31);
+  bf16x8 qf[4], kf[4], vf[4], dof[4];
+  load_frags(qf, prow(p.q, R, h), R.ok, hi);
+  load_frags(kf, prow(p.k, R, h), R.ok, hi);
+  load_frags(vf, prow(p.v, R, h), R.ok, hi);
+  load_frags(dof, prow(p.d_o, R, h), R.ok, hi);
+  float dl = 0.f;
+  {
+    const bf16_t* orow = prow(p.o, R, h);
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      const bf16x8 of = ldg8(orow + 16 * kd + 8 * hi, R.ok);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += bf2f((unsigned short)of[e]) * bf2f((unsigned short)dof[kd][e]);
+    }
+  }
+  dl += __shfl_xor(dl, 32);
+  const long long sidx = ((long long)R.b * p.heads + h) * S + R.pos;
+  const float lse = R.ok ? p.lse[sidx] : 0.f;
+  if (hi == 0) {
+    if (R.ok) p.delta[sidx] = dl;
+    sL[l31] = lse;
+    sDl[l31] = dl;
+  }
+  frags_to_lds(sK, kf, lane);
+  frags_to_lds(sQ, qf, lane);
+  frags_to_lds(sD, dof, lane);
+  __syncthreads();
+  // orientation 1: lane = query.  S^T = K Q^T, dP^T = V dO^T  ->  dQ^T = K^T dS^T
+  {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kd], qf[kd], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kd], dof[kd], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = (R.ok && crow(r, hi) / S == R.sub) ? __expf(s[r] * p.scale - lse) : 0.f;
+      s[r] = pv * (dp[r] - dl) * p.scale;
+    }
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 db = pack8(s, kk);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sK, 0, kk, lane), db, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sK, 1, kk, lane), db, a1, 0, 0, 0);
+    }
+    if (R.ok) store_rowT((bf16_t*)prow(p.dq, R, h), 0, 0, a0, a1, 1.f, hi);
+  }
+  // orientation 2: lane = key.  S = Q K^T, dP = dO V^T  ->  dV^T = dO^T P, dK^T = Q^T dS
+  {
+    f32x16 s, dp, pr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kd], kf[kd], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[kd], vf[kd], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = crow(r, hi);
+      const bool ok = R.ok && rr / S == R.sub;
+      const float pv = ok ? __expf(s[r] * p.scale - sL[rr]) : 0.f;
+      pr[r] = pv;
+      s[r] = pv * (dp[r] - sDl[rr]) * p.scale;
+    }
+    f32x16 k0, k1, v0, v1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) k0[r] = k1[r] = v0[r] = v1[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 pb = pack8(pr, kk), db = pack8(s, kk);
+      v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sD, 0, kk, lane), pb, v0, 0, 0, 0);
+      v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sD, 1, kk, lane), pb, v1, 0, 0, 0);
+      k0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sQ, 0, kk, lane), db, k0, 0, 0, 0);
+      k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sQ, 1, kk, lane), db, k1, 0, 0, 0);
+    }
+    if (R.ok) {
+      store_rowT((bf16_t*)prow(p.dk, R, h), 0, 0, k0, k1, 1.f, hi);
+      store_rowT((bf16_t*)prow(p.dv, R, h), 0, 0, v0, v1, 1.f, hi);
+    }
+  }
+}
+
+// packing applies to self-attention-shaped problems with a short power-of-two sequence
+__host__ inline int packed_seqs(const T2VAttn& p) {
+  if (p.Sq != p.Sk || p.Sq > 16 || (32 % p.Sq) != 0 || p.nbatch < 2) return 0;
+  return 32 / p.Sq;
+}
+
 int check_op(const char* fn, const char* name, const T2VAttnOperand& o) {
   if (!o.ptr || o.bdiv <= 0 || ((uintptr_t)o.ptr & 15) || (o.sstride % 8) || (o.bstride_hi % 8) || (o.bstride_lo % 8)) {
     t2v_set_error("%s: operand %s invalid (ptr %p, bdiv %d, strides must be multiples of 8 elements)", fn, name, o.ptr,
@@ -309,6 +484,13 @@ extern "C" int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream) {
   if (int e = check_op("t2v_attn_fwd", "k", p->k)) return e;
   if (int e = check_op("t2v_attn_fwd", "v", p->v)) return e;
   if (int e = check_op("t2v_attn_fwd", "o", p->o)) return e;
+  if (const int P = packed_seqs(*p)) {
+    T2V_CHECK_ARG(p->heads <= 65535, "t2v_attn_fwd: heads exceed grid limits (%d)", p->heads);
+    hipLaunchKernelGGL(attn_fwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
+                       p->Sq, P);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+  }
   dim3 grid((p->Sq + 31) / 32, p->heads, p->nbatch);
   T2V_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "t2v_attn_fwd: heads/nbatch exceed grid limits (%d, %d)", p->heads,
                 p->nbatch);
@@ -324,6 +506,13 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
   const char* names[] = {"q", "k", "v", "o", "d_o", "dq", "dk", "dv"};
   for (int i = 0; i < 8; ++i)
     if (int e = check_op("t2v_attn_bwd", names[i], *ops[i])) return e;
+  if (const int P = packed_seqs(*p)) {
+    T2V_CHECK_ARG(p->heads <= 65535, "t2v_attn_bwd: heads exceed grid limits (%d)", p->heads);
+    hipLaunchKernelGGL(attn_bwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
+                       p->Sq, P);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+  }
   T2V_CHECK_ARG(p->heads <= 65535 && p->nbatch <= 65535, "t2v_attn_bwd: heads/nbatch exceed grid limits");
   dim3 gq((p->Sq + 31) / 32, p->heads, p->nbatch);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
