@@ -356,7 +356,8 @@ def main():
                                    f"LoRA r={r} on all 574 Linear/Conv layers, batch 1 clip/GPU, 2 UNet passes/step, "
                                    f"dropout off (reference eval_train mode), text encoder: {text_mode}",
                        "global_batch": world, "parallelism": f"dp{world}", "graph_replay": use_graph,
-                       "trainable_params": trainer.opt.numel, "final_loss": final_loss},
+                       "trainable_params": sum(p.numel() for p in trainer.opt.params),
+                       "flat_gradient_elems": trainer.opt.numel, "final_loss": final_loss},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

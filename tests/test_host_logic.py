@@ -238,3 +238,39 @@ def test_lora_bank_projection_groups():
     keep = [p for p in params if p is not model["selfa"].to_k.lora_up.weight]
     lb.reorder(keep, plans2)
     assert "_t2v_group" not in model["selfa"].__dict__ and plans2[id(model["selfa"].to_q.lora_up.weight)][0].group is None
+
+
+def test_latent_cache_file_format(tmp_path):
+    """handle_cache_latents / CachedDataset (train.py:266-314, utils/dataset.py:589-603): one `cached_{i}.pt` per batch, the
+    'pixel_values' entry replaced by scaled latents (B,4,F,h,w) -> batch dim stripped, prompts kept, files listed sorted."""
+    from t2v_amd.utils.latent_cache import CachedDataset, handle_cache_latents
+
+    class _Dist:
+        def __init__(self, x):
+            self.x = x
+
+        def sample(self, eps=None):
+            return self.x[:, :4, ::8, ::8] * 2.0            # stand-in for the posterior sample at 1/8 resolution
+
+    class _Vae:
+        def encode(self, x):
+            class R:
+                latent_dist = _Dist(torch.cat([x, x[:, :1]], 1))
+            return R
+
+    batches = [{"pixel_values": torch.randn(1, 3, 3, 16, 16), "prompt_ids": torch.arange(77)[None, None], "text_prompt": [f"p{i}"]}
+               for i in range(3)]
+    assert handle_cache_latents(False, str(tmp_path), batches, 1, _Vae()) is None
+    dl = handle_cache_latents(True, str(tmp_path), [dict(b) for b in batches], 1, _Vae())
+    files = sorted(os.listdir(tmp_path / "cached_latents"))
+    assert files == ["cached_0.pt", "cached_1.pt", "cached_2.pt"]
+    ds = CachedDataset(str(tmp_path / "cached_latents"), map_location="cpu")
+    item = ds[1]
+    assert item["pixel_values"].shape == (4, 3, 2, 2) and item["prompt_ids"].shape == (1, 77) and item["text_prompt"] == "p1"
+    x = batches[1]["pixel_values"]
+    ref = (torch.cat([x[0], x[0][:, :1]], 1)[:, :4, ::8, ::8] * 2.0).permute(1, 0, 2, 3) * 0.18215
+    assert torch.allclose(item["pixel_values"], ref)
+    got = next(iter(torch.utils.data.DataLoader(ds, batch_size=1)))       # the loader the train loop consumes
+    assert got["pixel_values"].shape == (1, 4, 3, 2, 2)
+    dl2 = handle_cache_latents(True, str(tmp_path), None, 1, None, cached_latent_dir=str(tmp_path / "cached_latents"))
+    assert len(dl2.dataset) == 3 and len(dl.dataset) == 3

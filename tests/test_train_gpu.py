@@ -114,3 +114,24 @@ def test_graph_replay_equals_eager():
               f"pdiff {(t1.opt.flat_p - t2.opt.flat_p).abs().max().item():.3e}")
         assert rel < (1e-5 if i == 0 else 5e-3)      # later steps: AdamW's sign-like first updates amplify 1-ulp differences
     assert relerr(t2.opt.flat_p, t1.opt.flat_p) < 1e-2
+
+
+def test_cached_latents_path_equals_encode_path():
+    """train.py:741-746: with `cache_latents` the batch's 'pixel_values' already are the scaled latents (files written by
+    utils/latent_cache.py); the step must see exactly what the in-step VAE encode would have produced."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.models.vae import tensor_to_vae_latent
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4)
+    dparams = [p for p in dunet.parameters() if p.requires_grad]
+    batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=5, text_dim=64).items()}
+    tr = DenoiseTrainer(dunet, dvae, dparams, lr=1e-4)
+    with torch.no_grad():
+        l_enc = tr.loss_fn(batch)
+        lat = tensor_to_vae_latent(batch["pixel_values"], dvae, batch.get("vae_eps"))
+    cached = dict(batch)
+    cached["pixel_values"] = lat
+    tr.cache_latents = True
+    with torch.no_grad():
+        l_cached = tr.loss_fn(cached)
+    assert torch.equal(l_enc, l_cached)

@@ -124,16 +124,17 @@ class DenoiseTrainer:
 
     def __init__(self, unet, vae, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
                  scheduler=None, process_group=None, world_size=1, text_encoder=None, use_offset_noise=False,
-                 offset_noise_strength=0.1, rescale_schedule=False):
+                 offset_noise_strength=0.1, rescale_schedule=False, cache_latents=False):
         self.unet, self.vae = unet, vae
         self.text_encoder = text_encoder           # frozen CLIPTextModel (train.py:784-790); runs through stock torch ops
         self._aux_stream = None
         self.batch_passes = True                   # evaluate the two UNet passes of train.py:814 as one stacked forward
         self.use_offset_noise = use_offset_noise and not rescale_schedule      # train.py:750
         self.offset_noise_strength = offset_noise_strength
+        self.cache_latents = cache_latents         # batches come from utils/latent_cache.py: 'pixel_values' already ARE latents
+        self.scheduler = scheduler or DDPMScheduler()
         if rescale_schedule:
             self.scheduler.rescale_betas()         # train.py:689-690 (betas only; see schedulers.enforce_zero_terminal_snr)
-        self.scheduler = scheduler or DDPMScheduler()
         self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet)
         self.pg, self.world = process_group, world_size
         self._graph = None
@@ -152,8 +153,8 @@ class DenoiseTrainer:
             aux.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(aux), torch.no_grad():
                 ehs = self.text_encoder(ids)[0]
-        if "latents" in batch:                       # cache_latents path (train.py:744)
-            latents = batch["latents"]
+        if "latents" in batch or self.cache_latents:     # cache_latents path (train.py:741-746)
+            latents = batch["latents"] if "latents" in batch else batch["pixel_values"]
         else:
             latents = tensor_to_vae_latent(batch["pixel_values"], self.vae, batch.get("vae_eps"))
         noise = batch["noise"] if "noise" in batch else self.sample_noise(latents)
