@@ -6,7 +6,9 @@ Follows `train.py:720-836` (`finetune_unet`) and `train.py:848-879` (backward, c
   noisy    = add_noise(latents, noise, t)                  train.py:760
   two UNet passes, loss = mse0 + mse1                      train.py:814-834
   backward; clip_grad_norm_(unet.parameters(), 1.0); AdamW train.py:861-879
-The text encoder output is an input (`encoder_hidden_states`), SURVEY.md §8(f) row 2.
+The text encoder output is an input (`encoder_hidden_states`) unless a `text_encoder` is passed; with a TRAINABLE text
+encoder the reference's two passes differ (train.py:805-828): pass 0 sees the whole clip with DETACHED text states, pass 1
+sees frame 1 only with the trainable states ("train text information only on the spatial layers").
 """
 import torch
 import torch.nn.functional as F
@@ -15,7 +17,7 @@ from . import scheduler
 from .vae import tensor_to_vae_latent
 
 
-def finetune_unet_loss(unet, vae, batch, acp=None, cached_latents=None):
+def finetune_unet_loss(unet, vae, batch, acp=None, cached_latents=None, text_encoder=None, text_trainable=False):
     if cached_latents is None:
         with torch.no_grad():
             latents = tensor_to_vae_latent(batch["pixel_values"], vae, batch["vae_eps"])
@@ -24,10 +26,21 @@ def finetune_unet_loss(unet, vae, batch, acp=None, cached_latents=None):
     noise, timesteps = batch["noise"], batch["timesteps"]
     noisy = scheduler.add_noise(latents, noise, timesteps, acp)
     target = noise  # epsilon prediction (train.py:793-794)
-    ehs = batch["encoder_hidden_states"]
+    if text_encoder is not None:
+        ids = batch["prompt_ids"]
+        ehs = text_encoder(ids[0] if ids.dim() > 2 else ids)[0]         # train.py:784-790
+    else:
+        ehs = batch["encoder_hidden_states"]
     video_length = latents.shape[2]
+    should_truncate = video_length > 1 and text_trainable               # train.py:807
+    detached, trainable = ehs.clone().detach(), ehs.clone()             # train.py:811-812
     losses = []
     for i in range(2):
+        should_detach = noisy.shape[2] > 1 and i == 0                    # train.py:816
+        if should_truncate and i == 1:                                   # train.py:818-820
+            noisy = noisy[:, :, 1, :, :].unsqueeze(2)
+            target = target[:, :, 1, :, :].unsqueeze(2)
+        ehs = detached if should_detach else trainable
         pred = unet(noisy, timesteps, encoder_hidden_states=ehs).sample
         losses.append(F.mse_loss(pred.float(), target.float(), reduction="mean"))
         if video_length == 1 and i == 0:

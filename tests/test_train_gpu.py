@@ -135,3 +135,44 @@ def test_cached_latents_path_equals_encode_path():
     with torch.no_grad():
         l_cached = tr.loss_fn(cached)
     assert torch.equal(l_enc, l_cached)
+
+
+def test_trainable_text_encoder_two_pass_semantics():
+    """train.py:763-828 with a trainable text encoder: pass 0 = whole clip with detached text states, pass 1 = frame 1 only
+    with the trainable states; gradients must reach the text encoder's parameters through the native UNet's cross-attention
+    (CLIP itself runs through stock torch ops — SURVEY 8(f) row 2).  Oracle: the same recipe on CPU in fp32."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from oracle.train_step import finetune_unet_loss
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    ounet, ovae, dunet, dvae, _ = _build(r=4)
+    cfg = CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                         max_position_embeddings=77, bos_token_id=0, eos_token_id=999)
+    torch.manual_seed(3)
+    te_o = CLIPTextModel(cfg).eval()
+    te_d = copy.deepcopy(te_o)
+    for te in (te_o, te_d):
+        inner = getattr(te, "text_model", te)                  # transformers < 5 nests the stack under .text_model
+        te.requires_grad_(False)
+        inner.embeddings.requires_grad_(True)                  # what use_text_lora switches on (train.py:766-767)
+        inner.final_layer_norm.requires_grad_(True)
+    te_d = te_d.cuda()
+    batch = synthetic_batch(4, 64, 64, seed=21, text_dim=64)
+    batch.pop("encoder_hidden_states")
+    g = torch.Generator().manual_seed(4)
+    batch["prompt_ids"] = torch.randint(0, 1000, (1, 1, 77), generator=g)
+    lo, _ = finetune_unet_loss(ounet, ovae, batch, text_encoder=te_o, text_trainable=True)
+    lo.backward()
+    dparams = [p for p in dunet.parameters() if p.requires_grad] + [p for p in te_d.parameters() if p.requires_grad]
+    tr = DenoiseTrainer(dunet, dvae, dparams, lr=1e-4, text_encoder=te_d)
+    tr.opt.zero_grad()
+    ld = tr._fwd_bwd({k: v.cuda() for k, v in batch.items()})
+    rel = abs(ld.item() - lo.item()) / abs(lo.item())
+    print(f"text-trainable loss oracle {lo.item():.6f} native {ld.item():.6f} rel {rel:.2e}")
+    assert rel < 4e-3
+    od = dict(te_o.named_parameters())
+    for n, p in te_d.named_parameters():
+        if p.requires_grad:
+            e = relerr(p.grad, od[n].grad)
+            print("text grad", n, e)
+            assert od[n].grad.abs().max() > 0 and e < 0.2       # bf16 UNet between the loss and the text states

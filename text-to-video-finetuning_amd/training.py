@@ -143,7 +143,11 @@ class DenoiseTrainer:
     # ---- train.py:720-836
     def loss_fn(self, batch):
         ehs, aux = None, None
-        if "encoder_hidden_states" not in batch:     # train.py:784-790: frozen text encoder (no grad) — independent of the
+        text_trainable = self.text_encoder is not None and any(p.requires_grad for p in self.text_encoder.parameters())
+        if text_trainable:                           # train.py:763-790: text encoder in the autograd graph (main stream)
+            ids = batch["prompt_ids"]
+            ehs = self.text_encoder(ids[0] if ids.dim() > 2 else ids)[0]
+        elif "encoder_hidden_states" not in batch:   # train.py:784-790: frozen text encoder (no grad) — independent of the
             ids = batch["prompt_ids"]                # VAE encode, so it runs on an auxiliary stream beside it
             if ids.dim() > 2:
                 ids = ids[0]
@@ -166,7 +170,7 @@ class DenoiseTrainer:
         noisy = self.scheduler.add_noise(latents, noise, timesteps)
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)
-        else:
+        elif ehs is None:
             ehs = batch["encoder_hidden_states"]
         if self.scheduler.prediction_type == "epsilon":
             target = noise
@@ -175,6 +179,13 @@ class DenoiseTrainer:
         else:
             raise ValueError(f"Unknown prediction type {self.scheduler.prediction_type}")
         video_length = latents.shape[2]
+        if text_trainable and video_length > 1:
+            # train.py:805-828: pass 0 = whole clip with DETACHED text states; pass 1 = frame 1 only with the trainable
+            # states ("train text information only on the spatial layers")
+            pred = self.unet(noisy, timesteps, encoder_hidden_states=ehs.detach()).sample
+            l0 = mse_loss(pred.float(), target.float())
+            pred = self.unet(noisy[:, :, 1:2], timesteps, encoder_hidden_states=ehs).sample
+            return l0 + mse_loss(pred.float(), target[:, :, 1:2].float())
         if video_length > 1 and self.batch_passes:
             # train.py:814-834 runs the UNet twice on the same (noisy, t, text) and sums the two MSEs (text not trainable).
             # The two passes are independent, so they are evaluated as ONE forward over the stacked pair — the same
