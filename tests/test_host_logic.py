@@ -171,6 +171,10 @@ def test_stable_lora_flavour_cpu_semantics(tmp_path):
     h.save_lora_weights(m, str(tmp_path), step=3)
     f = tmp_path / "full_weights" / "3_lora_text_to_video_unet.safetensors"
     assert f.exists()
+    from safetensors.torch import load_file
+    web = load_file(str(tmp_path / "webui_3_lora_text_to_video.safetensors"))      # ModelScope key layout, fp16
+    assert len(web) == len(SL.lora_state_dict(m)) and all(v.dtype == torch.float16 for v in web.values())
+    assert "input_blocks.1.1.transformer_blocks.0.attn1.to_q.lora_A" in web and "input_blocks.1.0.in_layers.2.lora_B" in web
     for x_ in m.modules():
         if isinstance(x_, SL._LORA_TYPES):
             torch.nn.init.normal_(x_.lora_B, std=0.02)

@@ -184,3 +184,26 @@ def test_product_zero_terminal_snr_matches_oracle_restatement():
     acp = d.alphas_cumprod.clone()
     d.rescale_betas()
     assert torch.equal(d.alphas_cumprod, acp)      # reference quirk: add_noise is unaffected (train.py:689-690)
+
+
+def test_ms_webui_key_remap_matches_reference_converter():
+    """utils/convert_diffusers_to_original_ms_text_to_video.py: every state-dict key of the drop-in UNet and of a stable_lora
+    LoRA state dict maps to the name (and tensor rank) the REFERENCE converter produces (fixture generated by running it,
+    tests/golden/make_golden_keymap.py)."""
+    import json
+    from t2v_amd.models.unet_3d_condition import UNet3DConditionModel
+    from t2v_amd.stable_lora import lora as SL
+    from t2v_amd.utils.convert_diffusers_to_original_ms_text_to_video import convert_unet_state_dict
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ms_keymap.json")))
+    cfg = {k: (tuple(v) if isinstance(v, list) else v) for k, v in gold["config"].items()}
+    torch.manual_seed(0)
+    unet = UNet3DConditionModel(**cfg)
+    sd = unet.state_dict()
+    out = convert_unet_state_dict(sd)
+    assert list(sd.keys()) == list(gold["full"].keys())
+    assert {k: [nk, list(out[nk].shape)] for k, nk in zip(sd.keys(), out.keys())} == gold["full"]
+    SL.add_lora_to(unet, target_module=["Transformer2DModel", "ResnetBlock2D", "TransformerTemporalModel", "TemporalConvLayer"],
+                   search_class=[torch.nn.Linear, torch.nn.Conv2d, torch.nn.Conv3d], r=4)()
+    ld = SL.lora_state_dict(unet)
+    lout = convert_unet_state_dict(ld, strict_mapping=True)
+    assert {k: [nk, list(lout[nk].shape)] for k, nk in zip(ld.keys(), lout.keys())} == gold["stable_lora"]

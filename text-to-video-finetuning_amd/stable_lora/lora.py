@@ -6,7 +6,7 @@ The reference builds on `loralib` (un-vendored, absent offline); the few loralib
   Conv2d / Conv3d re-materialise `W + (B @ A).view(...) * scaling` every forward     stable_lora/lora.py:69-197
   (Conv3d: `.view(out, in, k, k, 1)` then `mean(dim=-2)`, merge force-disabled       :148-149,176-197)
   find_modules / add_lora_to (shares weight + bias, `module._modules[name] = l`)      :27-67,257-302
-  save_lora (full-weights safetensors) / load_lora / set_mode_group                    :304-387
+  save_lora (full-weights + webui safetensors) / load_lora / set_mode_group            :304-387
 On the device path the parents evaluate these layers through `models.leaves.run_layer` (attributes `lora_A`,
 `lora_B`, `scaling`, `merged`): the effective weight is formed once per call and the implicit-GEMM kernels run on it.
 """
@@ -195,18 +195,32 @@ def add_lora_to(model, target_module=UNET_REPLACE, search_class=(nn.Linear,), r=
 
 
 def save_lora(unet=None, text_encoder=None, save_text_weights=False, output_dir="output", lora_filename="lora.safetensors",
-              lora_bias="none", **_):
-    """Full-weights files only (`full_weights/{name}_unet.safetensors`); the webui key remap is §8(f) row 3."""
+              lora_bias="none", save_for_webui=True, only_webui=False, metadata=None, unet_dict_converter=None,
+              text_dict_converter=None):
+    """stable_lora/lora.py:304-362: `full_weights/{name}_unet.safetensors` (+ `_text_encoder`) in fp32 for further finetuning,
+    and `webui_{name}.safetensors`: the UNet LoRA keys renamed to the original ModelScope layout (converter), fp16."""
     from safetensors.torch import save_file
-    d = os.path.join(output_dir, "full_weights")
-    os.makedirs(d, exist_ok=True)
-    base = os.path.join(d, lora_filename)
-    if unet is not None:
-        save_file({k: v.detach().cpu().contiguous() for k, v in lora_state_dict(unet, lora_bias).items()},
-                  base + "_unet.safetensors")
-    if text_encoder is not None and save_text_weights:
-        save_file({k: v.detach().cpu().contiguous() for k, v in lora_state_dict(text_encoder, lora_bias).items()},
-                  base + "_text_encoder.safetensors")
+    ext = ".safetensors"
+    if not only_webui:
+        d = os.path.join(output_dir, "full_weights")
+        os.makedirs(d, exist_ok=True)
+        base = os.path.join(d, lora_filename)
+        for i, model in enumerate([unet, text_encoder]):
+            if model is None or (i == 1 and not save_text_weights):
+                continue
+            sd = {k: v.detach().cpu().contiguous() for k, v in lora_state_dict(model, lora_bias).items()}
+            save_file(sd, base + ("_text_encoder" if i == 1 else "_unet") + ext)
+    if save_for_webui and unet is not None:
+        if unet_dict_converter is None:
+            from ..utils.convert_diffusers_to_original_ms_text_to_video import convert_unet_state_dict as unet_dict_converter
+        out = unet_dict_converter(lora_state_dict(unet, lora_bias), strict_mapping=True)
+        if save_text_weights and text_encoder is not None:
+            if text_dict_converter is None:
+                from ..utils.convert_diffusers_to_original_ms_text_to_video import convert_text_enc_state_dict as text_dict_converter
+            out.update(text_dict_converter(lora_state_dict(text_encoder, lora_bias)))
+        out = {k: v.detach().to(torch.float16).cpu().contiguous() for k, v in out.items()}
+        os.makedirs(output_dir, exist_ok=True)
+        save_file(out, os.path.join(output_dir, f"webui_{lora_filename}{ext}"), metadata=metadata)
 
 
 def load_lora(model, lora_path):
