@@ -816,6 +816,10 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
     g_autotune = (e && e[0] == '0') ? 0 : 1;
   }
   if (!g_autotune) return heuristic_cfg(p);
+  if (const char* f = getenv("T2V_GEMM_FORCE_CFG")) {       // "tile,stages,split": pin one configuration (counter passes, A/B runs)
+    int t = 0, st = 2, sp = 1;
+    if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && t >= 0 && t <= 8) return DmaCfg{t, st, sp < 1 ? 1 : sp};
+  }
   TuneKey key;
   memset(&key, 0, sizeof(key));
   key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = p.n_split > 0; key.out_mode = p.out_mode;
