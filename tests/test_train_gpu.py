@@ -176,3 +176,24 @@ def test_trainable_text_encoder_two_pass_semantics():
             e = relerr(p.grad, od[n].grad)
             print("text grad", n, e)
             assert od[n].grad.abs().max() > 0 and e < 0.2       # bf16 UNet between the loss and the text states
+
+
+def test_plain_backward_joins_factor_gradient_stream():
+    """Driven the reference's way (loss.backward(); clip_grad_norm_; optimizer.step() — train.py:861-877) the side-stream
+    factor-gradient launches must be joined by the end of backward: the end-of-backward callback leaves nothing pending."""
+    import t2v_amd.functional as F
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4)
+    dparams = [p for p in dunet.parameters() if p.requires_grad]
+    tr = DenoiseTrainer(dunet, dvae, dparams, lr=1e-4)
+    batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=9, text_dim=64).items()}
+    tr.opt.zero_grad()
+    tr.opt.refresh_bf16()
+    loss = tr.loss_fn(batch)
+    loss.backward()
+    assert F._side["refs"] == [] and not F._side["cb"]
+    gn = torch.nn.utils.clip_grad_norm_(dparams, 1.0)            # reads the gradients on the current stream
+    tr.opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(gn) and gn > 0

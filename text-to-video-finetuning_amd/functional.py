@@ -313,7 +313,7 @@ def _unprep_weight_grad(dwp, weight, cfg):
 # Factor-gradient launches (dU, dD) feed only the flat gradient buffer, i.e. they are off the critical path of
 # backward: they are issued on a side stream (forked after dt, joined once before the optimizer) so that they overlap the
 # latency-bound main chain.  Inside a HIP-graph capture this becomes a parallel branch of the graph.
-_side = {"stream": None, "refs": [], "enabled": os.environ.get("T2V_WGRAD_STREAM", "1") != "0"}
+_side = {"stream": None, "refs": [], "enabled": os.environ.get("T2V_WGRAD_STREAM", "1") != "0", "cb": False}
 
 
 def _side_stream():
@@ -327,6 +327,29 @@ def join_side_stream():
     if _side["stream"] is not None and _side["refs"]:
         torch.cuda.current_stream().wait_stream(_side["stream"])
     _side["refs"].clear()
+
+
+def _end_of_backward():
+    _side["cb"] = False
+    join_side_stream()
+
+
+def _fork_side(work, keep):
+    """Run `work()` (factor-gradient launches) on the side stream, ordered after everything issued so far on the current
+    stream.  The join is queued as an end-of-backward callback of the running autograd pass, so that whoever reads the
+    gradients next (clip_grad_norm_, any optimizer, an all-reduce) sees them complete — also when the modules are driven by
+    the reference's own train loop instead of DenoiseTrainer."""
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        work()
+    _side["refs"].append(keep)               # keep operands alive until join_side_stream()
+    if not _side["cb"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+            _side["cb"] = True
+        except RuntimeError:                 # not inside a backward pass (direct call of a Function's backward): join now
+            join_side_stream()
 
 
 def _lowrank_update(y, t, u, M, N, r, scale):
@@ -458,11 +481,7 @@ class _LoraLayer(torch.autograd.Function):
                      out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M)))
 
         if _side["enabled"]:
-            side = _side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                wgrads()
-            _side["refs"].append((dy, t, dt, x))      # keep operands alive until join_side_stream()
+            _fork_side(wgrads, (dy, t, dt, x))
         else:
             wgrads()
         return dx, None, None, None, None, drb, dres, None, None, None
@@ -561,11 +580,7 @@ class _LoraGroup(torch.autograd.Function):
                 nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
 
         if _side["enabled"]:
-            side = _side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                wgrads()
-            _side["refs"].append((keep, t, dt, x))
+            _fork_side(wgrads, (keep, t, dt, x))
         else:
             wgrads()
         return (dx, None, None) + (None,) * n

@@ -107,6 +107,8 @@ class FlatAdamW:
         return self.sumsq.sqrt()
 
     def step(self, grad_scale=1.0):
+        from .functional import join_side_stream
+        join_side_stream()                 # no-op after a normal backward (its end-of-backward callback already joined)
         s = nv.stream()
         self.sumsq.zero_()
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
