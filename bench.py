@@ -335,7 +335,8 @@ def main():
                            "step (implicit-GEMM, LDS-DMA ring); eager instrumented pass, HIP events on the launch stream",
                     achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     launches=rr["launches"], algorithmic_gflop_per_step=round(rr["flops"] / 1e9, 1),
-                    kernel_ms_per_step=round(rr["ms"], 2), traffic=pmc_traffic(),
+                    kernel_ms_per_step=round(rr["ms"], 2), traffic=(pmc_traffic() or {}).get("hbm_bytes_per_launch"),
+                    traffic_detail=pmc_traffic(),
                     secondary={"kernel": "gemm_kernel<..,AT|BT> - K-major / transposed-operand launches (factor gradients of strided convs, "
                                          "VAE attention P.V); the LoRA factor gradients proper are north_star_kernels.lora_factor_gradients",
                                "launches": km["launches"], "algorithmic_gflop_per_step": round(km["flops"] / 1e9, 1),
