@@ -326,7 +326,7 @@ def main():
     final_loss = float(loss.item())
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:      # per-kernel instrumentation belongs to the 1-GPU line
         both = gemm_roofline(trainer, batch)
         rr, km = both["nn"], both["kmajor"]
         ach = rr["flops"] / (rr["ms"] * 1e-3) / 1e12
