@@ -6,7 +6,9 @@
  * that one reference call site dispatches to (cited per function).  Conventions:
  *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer;
  *   - asynchronous on the given hipStream_t, no internal synchronisation, no allocation
- *     (graph-capture safe); caller owns all memory incl. workspaces;
+ *     (graph-capture safe); caller owns all memory incl. workspaces.  One exception, outside stream
+ *     capture only: the FIRST t2v_gemm call of a problem signature times its tile candidates
+ *     (device synchronisation + HIP events, a few ms; T2V_GEMM_AUTOTUNE=0 selects tiles heuristically);
  *   - returns 0 on success, negative T2V_E* on error; t2v_last_error() gives a thread-local text;
  *   - activations are "token matrices": row-major [rows, ld] bf16, channels contiguous
  *     (channels-last).  rows = images*H*W.  `ld` = row stride in ELEMENTS;
