@@ -358,3 +358,56 @@ def test_lowrank_window_update(nimg, H, W, KH, KW, C, r):
     nv.call("t2v_lowrank_window_update", yd.data_ptr(), C, td.data_ptr(), r, Dd.data_ptr(), taps * C, C_.byref(geom), rows, C, r,
             0.5, nv.stream())
     assert relerr(yd, ref.view(rows, C)) < 1e-2
+
+
+def test_dropout_mask_protocol_matches_cpu_restatement():
+    """The counter-based keep decision (csrc/common.h drop_keep) is bit-identical to oracle/dropout.py — the mask that is
+    'identically defined on CPU and GPU' (SURVEY 8d)."""
+    import t2v_amd.native as nv
+    from oracle.dropout import keep_mask
+    rows, cols, p, seed = 257, 320, 0.3, 0x1234ABCD5
+    x = torch.ones(rows, cols, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty_like(x)
+    nv.call("t2v_dropout_mask", x.data_ptr(), cols, y.data_ptr(), cols, rows, cols, p, seed, nv.stream())
+    keep = keep_mask(seed, rows, cols, p)
+    assert torch.equal(y.cpu() != 0, keep)
+    assert torch.allclose(y.cpu().float()[keep], torch.tensor(1.0 / (1.0 - p)).to(torch.bfloat16).float())
+
+
+def test_groupnorm_dropout_matches_masked_reference():
+    """GroupNorm+SiLU+Dropout (TemporalConvLayer conv2-4, models/unet_3d_blocks.py:312…) with the protocol mask, fwd + bwd."""
+    import t2v_amd.functional as F
+    from oracle.dropout import keep_mask
+    nd, rows, C, G, p, seed = 2, 96, 320, 32, 0.1, 777
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(nd * rows, C, generator=g) + 0.2); gm = torch.randn(C, generator=g); bt = torch.randn(C, generator=g)
+    dy = _bf(torch.randn(nd * rows, C, generator=g))
+    m = keep_mask(seed, nd * rows, C, p).float() / (1.0 - p)
+    xr = x.float().requires_grad_()
+    y3 = TF.silu(TF.group_norm(xr.view(nd, rows, C).permute(0, 2, 1), G, gm, bt, 1e-5)).permute(0, 2, 1).reshape(nd * rows, C) * m
+    y3.backward(dy.float())
+    xd = _dev(x)
+    y = F.group_norm(xd, gm.cuda(), bt.cuda(), G, 1e-5, True, nd, p, seed)
+    y.backward(dy.cuda())
+    assert torch.equal(y.detach().cpu() != 0, (y3 != 0))          # same elements dropped
+    assert relerr(y, y3) < TOL and relerr(xd.grad, xr.grad) < 3e-2
+
+
+def test_lora_branch_dropout_in_gemm_epilogue():
+    """y = residual + dropout(scale * up(t)) (utils/lora.py:57-62 with dropout_p > 0): mask applied in the GEMM epilogue and
+    re-applied to dy in backward."""
+    import t2v_amd.functional as F
+    from oracle.dropout import keep_mask
+    M, N, r, p, seed, s = 300, 320, 16, 0.1, 4242, 0.7
+    g = torch.Generator().manual_seed(8)
+    t = _bf(torch.randn(M, r, generator=g)); w = _bf(torch.randn(N, r, generator=g) * 0.3); res = _bf(torch.randn(M, N, generator=g))
+    dy = _bf(torch.randn(M, N, generator=g))
+    m = keep_mask(seed, M, N, p).float() / (1.0 - p)
+    tr, wr = t.float().requires_grad_(), w.float().requires_grad_()
+    yr = res.float() + (s * (tr @ wr.t())) * m
+    yr.backward(dy.float())
+    td, wd = _dev(t), _dev(w)
+    y = F.conv_linear(td, wd, None, F.LINEAR, None, res.cuda(), alpha=s, drop_p=p, drop_seed=seed)
+    y.backward(dy.cuda())
+    assert relerr(y, yr) < TOL
+    assert relerr(td.grad, tr.grad) < 3e-2 and relerr(wd.grad, wr.grad) < 3e-2
