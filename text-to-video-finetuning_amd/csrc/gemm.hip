@@ -757,6 +757,8 @@ int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
     case 6: rc = launch_dma<256, 320, 4, 2, 2>(q, s); break;
     case 7: rc = launch_dma<256, 256, 4, 2, 2>(q, s); break;
     case 8: rc = s2 ? launch_dma<128, 256, 2, 2, 2>(q, s) : launch_dma<128, 256, 2, 2, 3>(q, s); break;
+    // N = 320 + 16 rank columns (LoRA down-projection riding in the base launch) in ONE tile instead of six 64-wide ones
+    case 9: rc = launch_dma<128, 384, 2, 2, 2>(q, s); break;
     default: rc = s2 ? launch_dma<128, 32, 4, 1, 2>(q, s) : launch_dma<128, 32, 4, 1, 4>(q, s); break;
   }
   if (rc) return rc;
@@ -818,7 +820,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   if (!g_autotune) return heuristic_cfg(p);
   if (const char* f = getenv("T2V_GEMM_FORCE_CFG")) {       // "tile,stages,split": pin one configuration (counter passes, A/B runs)
     int t = 0, st = 2, sp = 1;
-    if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && t >= 0 && t <= 8) return DmaCfg{t, st, sp < 1 ? 1 : sp};
+    if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && t >= 0 && t <= 9) return DmaCfg{t, st, sp < 1 ? 1 : sp};
   }
   TuneKey key;
   memset(&key, 0, sizeof(key));
@@ -838,9 +840,9 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   const int tiles_lo = p.N <= 32 ? 3 : 0, tiles_hi = p.N <= 32 ? 3 : 2;
   std::vector<int> tl;
   for (int t = tiles_lo; t <= tiles_hi; ++t) tl.push_back(t);
-  static const int BMs[9] = {128, 128, 64, 128, 256, 128, 256, 256, 128}, BNs[9] = {128, 64, 64, 32, 128, 320, 320, 256, 256};
+  static const int BMs[10] = {128, 128, 64, 128, 256, 128, 256, 256, 128, 128}, BNs[10] = {128, 64, 64, 32, 128, 320, 320, 256, 256, 384};
   if (p.N > 64 && (long long)p.M * p.N >= (long long)256 * 128 * 128) tl.push_back(4);   // big outputs: 8-wave 256x128 tile
-  for (int t = 5; t <= 8; ++t) {
+  for (int t = 5; t <= 9; ++t) {
     if (p.N < 256 || p.M < BMs[t]) continue;
     long long padded = (long long)((p.N + BNs[t] - 1) / BNs[t]) * BNs[t];
     if (padded * 100 > (long long)p.N * 115) continue;                     // <= 15 % padded columns
@@ -851,7 +853,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
     if (t < 3 && p.N <= 64 && BNs[t] > 64) continue;
     long long tiles = (long long)((p.M + BMs[t] - 1) / BMs[t]) * ((p.N + BNs[t] - 1) / BNs[t]);
     for (int st : {0, 2}) {
-      if (st == 0 && (t == 5 || t == 6 || t == 7)) continue;                 // these only exist as 2-stage rings (LDS)
+      if (st == 0 && (t == 5 || t == 6 || t == 7 || t == 9)) continue;       // these only exist as 2-stage rings (LDS)
       cand.push_back(DmaCfg{t, st, 1});
       if (can_split && st == 0) {
         for (int sp : {2, 4, 8, 16}) {
