@@ -278,3 +278,34 @@ def test_latent_cache_file_format(tmp_path):
     assert got["pixel_values"].shape == (1, 4, 3, 2, 2)
     dl2 = handle_cache_latents(True, str(tmp_path), None, 1, None, cached_latent_dir=str(tmp_path / "cached_latents"))
     assert len(dl2.dataset) == 3 and len(dl.dataset) == 3
+
+
+def test_flat_buffer_rehoming_after_device_round_trip():
+    """lora_bank.is_homed / rehome: after `module.cpu()`-style re-allocation (the reference's save_pipe, train.py:417-442) the
+    Parameters are pointed back at their flat-buffer views with their CURRENT values; foreign gradients are merged, not lost."""
+    import t2v_amd.lora_bank as lb
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(6, 4)
+    params = list(lin.parameters())
+    flat_p, flat_g = torch.zeros(64), torch.zeros(64)
+    homes, off = [], 0
+    for p in params:
+        v, g = flat_p[off:off + p.numel()].view(p.shape), flat_g[off:off + p.numel()].view(p.shape)
+        v.copy_(p.detach()); p.data = v; p.grad = g
+        homes.append((p, v, g.detach())); off += p.numel()          # as FlatAdamW does
+    assert lb.is_homed(homes)
+    lin._apply(lambda t: t.clone())                 # what .cpu()/.to(device) do: every parameter (and grad) gets a new storage
+    assert not lb.is_homed(homes)
+    with torch.no_grad():
+        lin.weight.add_(1.0)                        # value changed while detached
+    lin.weight.grad = torch.full_like(lin.weight, 0.5)        # a gradient that landed outside the flat buffer
+    lb.rehome(homes)
+    assert lb.is_homed(homes)
+    assert lin.weight.data_ptr() == homes[0][1].data_ptr() and lin.weight.grad.data_ptr() == homes[0][2].data_ptr()
+    assert torch.equal(flat_p[:24].view(4, 6), lin.weight.detach()) and torch.all(flat_g[:24] == 0.5)
+    flat_p[:24] += 1.0                              # an optimizer update through the flat buffer is visible in the module
+    assert torch.equal(lin.weight.detach(), flat_p[:24].view(4, 6))
+    lin.zero_grad(set_to_none=True)                 # torch's default: grads become None -> re-attached, nothing to merge
+    assert not lb.is_homed(homes)
+    lb.rehome(homes)
+    assert lin.weight.grad.data_ptr() == homes[0][2].data_ptr()

@@ -208,3 +208,28 @@ def attach(plans, flat_p16, flat_g, offsets):
         g.down_g = flat_g[d0: d0 + g.rp * g.cin_p].view(g.rp, g.cin_p)
         g.up_w16 = flat_p16[u0: u0 + g.rp * g.npad].view(g.rp, g.npad)
         g.up_g = flat_g[u0: u0 + g.rp * g.npad].view(g.rp, g.npad)
+
+
+def is_homed(homes):
+    """True if the Parameters (first and last are enough: `Module._apply` moves all of them) still alias their flat-buffer views."""
+    for p, v, g in (homes[0], homes[-1]):
+        if p.data_ptr() != v.data_ptr() or p.grad is None or p.grad.data_ptr() != g.data_ptr():
+            return False
+    return True
+
+
+def rehome(homes):
+    """Point every Parameter (and its .grad) back at its flat-buffer view, keeping the CURRENT parameter values.
+    Needed after `model.cpu()` / `.to(device)` round trips — the reference's `save_pipe` does one at every checkpoint
+    (train.py:417-442) — which re-allocate the parameter storages and would silently detach them from the optimizer."""
+    with torch.no_grad():
+        for p, v, g in homes:
+            if p.data_ptr() != v.data_ptr():
+                v.copy_(p.detach().to(device=v.device, dtype=v.dtype))
+                p.data = v
+            # `g` itself is never handed out: Module._apply swaps the .data of the very tensor object that is p.grad
+            if p.grad is None:
+                p.grad = g.detach()
+            elif p.grad.data_ptr() != g.data_ptr():      # a gradient autograd (or a device move) put elsewhere: keep its values
+                g.copy_(p.grad.detach().to(device=g.device, dtype=g.dtype))
+                p.grad = g.detach()

@@ -81,6 +81,7 @@ class FlatAdamW:
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         off, offsets = 0, {}
+        self._homes = []
         for p, k in zip(plist, sizes):
             pl = plans.get(id(p))
             if pl:
@@ -92,23 +93,35 @@ class FlatAdamW:
             view.copy_(p.detach().float())
             p.data = view
             p.grad = gview
+            self._homes.append((p, view, gview.detach()))   # own alias of the gradient slot (p.grad's object can be re-pointed)
             offsets[id(p)] = off
             off += k
         lora_bank.attach(plans, self.flat_p16, self.flat_g, offsets)
         self.refresh_bf16()
 
+    def _ensure_homed(self):
+        from . import lora_bank
+        if not lora_bank.is_homed(self._homes):      # e.g. after the reference's save_pipe (`unet.cpu()` ... `.to(device)`)
+            lora_bank.rehome(self._homes)
+
     def refresh_bf16(self):
+        self._ensure_homed()
         nv.call("t2v_cast_f32_to_bf16", self.flat_p.data_ptr(), self.flat_p16.data_ptr(), self.numel, nv.stream())
 
     def zero_grad(self, set_to_none=False):
+        self._ensure_homed()
         self.flat_g.zero_()
 
     def grad_norm(self):
         return self.sumsq.sqrt()
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, refresh=True):
+        """clip + AdamW on the flat buffers (2 kernels).  `refresh`: re-derive the bf16 copies of the LoRA factors right away,
+        so that a plain `loss.backward(); optimizer.step()` loop (the reference's) needs no extra call; DenoiseTrainer
+        refreshes inside its captured step instead."""
         from .functional import join_side_stream
         join_side_stream()                 # no-op after a normal backward (its end-of-backward callback already joined)
+        self._ensure_homed()
         s = nv.stream()
         self.sumsq.zero_()
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
@@ -118,6 +131,8 @@ class FlatAdamW:
                 self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 self.sumsq.data_ptr() if clip else None, float(self.max_grad_norm or 0.0), float(grad_scale),
                 self.step_count.data_ptr(), s)
+        if refresh:
+            self.refresh_bf16()
 
 
 class DenoiseTrainer:
@@ -222,7 +237,7 @@ class DenoiseTrainer:
     def _exchange_and_update(self):
         from .parallel import allreduce_flat_grads
         scale, _ = allreduce_flat_grads(self.opt.flat_g, self.world, self.pg)   # RCCL over xGMI: one flat buffer
-        self.opt.step(grad_scale=scale)
+        self.opt.step(grad_scale=scale, refresh=False)     # _fwd_bwd refreshes the bf16 copies (inside the captured step)
 
     def train_step(self, batch):
         self.opt.zero_grad()
