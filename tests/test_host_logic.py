@@ -309,3 +309,49 @@ def test_flat_buffer_rehoming_after_device_round_trip():
     assert not lb.is_homed(homes)
     lb.rehome(homes)
     assert lin.weight.grad.data_ptr() == homes[0][2].data_ptr()
+
+
+@pytest.mark.parametrize("kind,steps", [("ddim", 7), ("dpm", 7), ("dpm", 20)])
+def test_sampling_schedulers_follow_the_exact_trajectory(kind, steps):
+    """With an exact epsilon model (x0 known) both samplers must stay on x_t = alpha_t x0 + sigma_t eps and end at x0:
+    DDIM by construction, DPM-Solver++(2M) because its update is exact for a constant data prediction."""
+    from t2v_amd.schedulers import DDIMScheduler, DPMSolverMultistepScheduler
+    sch = DDIMScheduler() if kind == "ddim" else DPMSolverMultistepScheduler()
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 3, 4, 4, generator=g, dtype=torch.float64)
+    eps = torch.randn(1, 4, 3, 4, 4, generator=g, dtype=torch.float64)
+    ts = sch.set_timesteps(steps)
+    assert len(ts) == steps and int(ts[0]) == 999 and all(int(a) > int(b) for a, b in zip(ts, ts[1:]))
+    acp = sch.alphas_cumprod.double()
+    x = acp[ts[0]].sqrt() * x0 + (1 - acp[ts[0]]).sqrt() * eps
+    for i, t in enumerate(ts):
+        model_eps = (x - acp[t].sqrt() * x0) / (1 - acp[t]).sqrt()           # what a perfect model predicts at (x, t)
+        x = sch.step(model_eps, t, x)
+        if i + 1 < len(ts):
+            tn = ts[i + 1]
+            assert torch.allclose(x, acp[tn].sqrt() * x0 + (1 - acp[tn]).sqrt() * eps, atol=1e-9)
+    assert torch.allclose(x, x0, atol=1e-9)
+
+
+def test_sampler_cfg_loop_with_a_stub_unet():
+    """TextToVideoSampler: CFG doubles the batch (uncond | cond), guidance mixes the two halves, the scheduler is stepped once
+    per timestep; with a model that returns the true epsilon of a known x0 the loop lands on x0 for any guidance scale."""
+    from t2v_amd.pipelines import TextToVideoSampler
+    from t2v_amd.schedulers import DPMSolverMultistepScheduler
+    sch = DPMSolverMultistepScheduler()
+    x0 = torch.randn(1, 4, 2, 4, 4, generator=torch.Generator().manual_seed(1))
+    calls = []
+
+    class Stub:
+        config = type("c", (), {"in_channels": 4})()
+
+        def __call__(self, x, t, encoder_hidden_states=None):
+            calls.append((x.shape[0], int(t[0]), encoder_hidden_states.shape[0]))
+            acp = sch.alphas_cumprod[int(t[0])]
+            return type("o", (), {"sample": (x - acp.sqrt() * x0) / (1 - acp).sqrt()})()
+
+    pe, ne = torch.randn(1, 77, 8), torch.zeros(1, 77, 8)
+    out = TextToVideoSampler(Stub(), sch)(pe, ne, num_frames=2, height=32, width=32, num_inference_steps=6, guidance_scale=7.5,
+                                          generator=torch.Generator().manual_seed(2))
+    assert out.shape == (1, 4, 2, 4, 4) and torch.allclose(out, x0, atol=1e-4)
+    assert len(calls) == 6 and all(c[0] == 2 and c[2] == 2 for c in calls) and calls[0][1] == 999

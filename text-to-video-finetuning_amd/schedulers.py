@@ -54,3 +54,84 @@ def _rescale_betas(self):
 
 
 DDPMScheduler.rescale_betas = _rescale_betas
+
+
+# --------------------------------------------------------------------------- sampling schedulers
+class _SamplerBase(DDPMScheduler):
+    """Shared timestep grid of the sampling schedulers: `num_inference_steps` points of [0, T-1], descending
+    ("linspace" spacing).  alpha_t = sqrt(abar_t), sigma_t = sqrt(1 - abar_t); the step past the last point is abar = 1."""
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        ts = torch.linspace(0, self.num_train_timesteps - 1, num_inference_steps + 1).round().long().flip(0)[:-1]
+        self.timesteps = ts.to(device) if device is not None else ts
+        self.num_inference_steps = num_inference_steps
+        self._step_index = 0
+        self._prev_x0 = None
+        self._prev_lambda = None
+        return self.timesteps
+
+    def _abar(self, t):
+        return self.alphas_cumprod[t].double() if t >= 0 else torch.tensor(1.0, dtype=torch.float64)
+
+    def _x0(self, model_output, sample, t):
+        a, s = self._abar(t).sqrt(), (1 - self._abar(t)).sqrt()
+        if self.prediction_type == "epsilon":
+            return (sample - s.to(sample.dtype) * model_output) / a.to(sample.dtype)
+        if self.prediction_type == "v_prediction":
+            return a.to(sample.dtype) * sample - s.to(sample.dtype) * model_output
+        raise ValueError(f"Unknown prediction type {self.prediction_type}")
+
+    def _next_t(self):
+        i = self._step_index
+        return int(self.timesteps[i + 1]) if i + 1 < len(self.timesteps) else -1
+
+
+class DDIMScheduler(_SamplerBase):
+    """Deterministic DDIM (eta = 0): x_prev = alpha_prev * x0 + sigma_prev * eps, with (x0, eps) recovered from the model
+    output at t.  Used by `inference.py` style sampling; exact along the true trajectory for an exact model."""
+
+    def step(self, model_output, timestep, sample):
+        t, tp = int(timestep), self._next_t()
+        x0 = self._x0(model_output, sample, t)
+        a_t, s_t = self._abar(t).sqrt(), (1 - self._abar(t)).sqrt()
+        eps = (sample - a_t.to(sample.dtype) * x0) / s_t.to(sample.dtype)
+        a_p, s_p = self._abar(tp).sqrt(), (1 - self._abar(tp)).sqrt()
+        self._step_index += 1
+        return a_p.to(sample.dtype) * x0 + s_p.to(sample.dtype) * eps
+
+
+class DPMSolverMultistepScheduler(_SamplerBase):
+    """DPM-Solver++(2M), data-prediction form, midpoint variant, first-order warm-up and first-order final step for short
+    schedules — the sampler the reference's validation uses (`DPMSolverMultistepScheduler.from_config`, train.py:923-926;
+    algorithm of Lu et al. 2022, eq. for the multistep second-order update):
+        lambda_t = log(alpha_t / sigma_t), h = lambda_t - lambda_s
+        first  : x_t = (sigma_t/sigma_s) x_s - alpha_t (e^{-h} - 1) D_s
+        second : D1 = (D_s - D_s') / r0, r0 = (lambda_s - lambda_s') / h ;  x_t = first - 0.5 alpha_t (e^{-h} - 1) D1"""
+
+    def __init__(self, *args, solver_order=2, lower_order_final=True, **kw):
+        super().__init__(*args, **kw)
+        self.solver_order, self.lower_order_final = solver_order, lower_order_final
+
+    def step(self, model_output, timestep, sample):
+        t, tp = int(timestep), self._next_t()
+        x0 = self._x0(model_output, sample, t)
+        a_s, s_s = self._abar(t).sqrt(), (1 - self._abar(t)).sqrt()
+        a_t, s_t = self._abar(tp).sqrt(), (1 - self._abar(tp)).sqrt()
+        lam_s = torch.log(a_s / s_s)
+        last = tp < 0
+        if last:                                         # sigma_t = 0: the update collapses onto the data prediction
+            out = x0
+        else:
+            lam_t = torch.log(a_t / s_t)
+            h = lam_t - lam_s
+            em1 = torch.expm1(-h)
+            out = (s_t / s_s).to(sample.dtype) * sample - (a_t * em1).to(sample.dtype) * x0
+            second = (self.solver_order >= 2 and self._prev_x0 is not None
+                      and not (self.lower_order_final and self.num_inference_steps < 15 and self._step_index == len(self.timesteps) - 2))
+            if second:
+                r0 = (lam_s - self._prev_lambda) / h
+                d1 = (x0 - self._prev_x0) / r0.to(sample.dtype)
+                out = out - (0.5 * a_t * em1).to(sample.dtype) * d1
+        self._prev_x0, self._prev_lambda = x0, lam_s
+        self._step_index += 1
+        return out
