@@ -1,6 +1,6 @@
 // norm.hip — GroupNorm(+SiLU) and LayerNorm, forward and backward, over channels-last bf16 token matrices.
-// HBM-bound streaming kernels: 16-byte (8 x bf16) loads per lane, fp32 statistics, wave/LDS reductions,
-// one atomic per (block, group).  A GroupNorm "domain" is the set of rows one statistic spans
+// HBM-bound streaming kernels: 16-byte (8 x bf16) loads per lane, fp32 statistics, fixed-order LDS reductions
+// (no floating-point atomics on the statistics).  A GroupNorm "domain" is the set of rows one statistic spans
 // (H*W rows for per-frame norms, F*H*W rows for the 5-D temporal norms) — see t2v_abi.h.
 #include "common.h"
 
@@ -8,7 +8,8 @@ namespace {
 
 // ------------------------------------------------------------------ GroupNorm statistics
 // grid (nsplit, ndomains); each block reduces a slab of rows of one domain over all channels and writes its
-// per-group partial (no atomics: fixed-order LDS reduction + a finalize pass => bit-reproducible statistics).
+// per-group partial; the last block of a domain to finish sums the partials in index order (see the hand-off at the end of
+// the kernel) => bit-reproducible statistics without a separate finalize launch.
 constexpr int GN_MAX_SPLIT = 256;
 
 template <bool BWD>
