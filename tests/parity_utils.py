@@ -1,0 +1,138 @@
+"""Shared helpers of the model-level parity tests (test infrastructure; imports oracle/ — never imported by the product).
+
+Everything random is drawn on the HOST from fixed seeds (torch CPU generators), so the oracle results of the full-size
+configurations can be computed once in the build container (tests/golden/make_oracle_step.py) and shipped as small
+fixtures: the GPU box rebuilds the identical weights/inputs, checks their checksum against the fixture, and compares the
+native path with the recorded oracle loss / LoRA-factor gradients.  If the checksum does not match (different torch
+build), the tests fall back to running the oracle live.
+"""
+import os
+
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SMALL = dict(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, attention_head_dim=64)
+VAE_SMALL = dict(block_out_channels=(32, 64, 64, 64))
+CONFIGS = {            # BASELINE.json configs: name -> (frames, H, W, lora rank)
+    "c1": (8, 128, 128, 4),
+    "c2": (16, 256, 256, 16),
+}
+
+
+def build_oracle(full=True, r=4, lora_up_scale=0.0, seed=0):
+    """CPU fp32 oracle UNet (+ LoRA on every Linear/Conv, utils/lora.py:393-480) and VAE encoder, host-seeded."""
+    from oracle.lora import inject_trainable_lora_extended
+    from oracle.unet3d import UNet3DConditionModel
+    from oracle.vae import AutoencoderKLEncoder
+    from oracle.weights import randomize_lora_up, randomize_temporal_conv4
+    torch.manual_seed(seed)
+    unet = UNet3DConditionModel(**({} if full else SMALL))
+    randomize_temporal_conv4(unet)
+    vae = AutoencoderKLEncoder(**({} if full else VAE_SMALL)).eval()
+    unet.requires_grad_(False)
+    vae.requires_grad_(False)
+    _, names = inject_trainable_lora_extended(unet, {"UNet3DConditionModel"}, r=r)
+    randomize_lora_up(unet, scale=lora_up_scale)     # 0 => the reference's init (up = 0, utils/lora.py:55)
+    for m in unet.modules():                         # eval_train mode (train.py:779-781): dropout off
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    unet.train()
+    return unet, vae, len(names)
+
+
+def build_native(ounet, ovae, full=True, r=4):
+    """The drop-in UNet/VAE on cuda:0 carrying exactly the oracle's weights (frozen + LoRA factors)."""
+    import t2v_amd  # noqa: F401
+    from t2v_amd.models.unet_3d_condition import UNet3DConditionModel
+    from t2v_amd.models.vae import AutoencoderKL
+    from t2v_amd.utils.lora import inject_trainable_lora_extended
+    with torch.device("meta"):
+        dunet = UNet3DConditionModel(**({} if full else SMALL))
+        dvae = AutoencoderKL(**({} if full else VAE_SMALL))
+    dunet = dunet.to_empty(device="cuda")
+    dvae = dvae.to_empty(device="cuda")
+    dunet.requires_grad_(False)
+    dvae.requires_grad_(False)
+    inject_trainable_lora_extended(dunet, {"UNet3DConditionModel"}, r=r)
+    dunet.load_state_dict(ounet.state_dict(), strict=True)
+    dvae.load_state_dict(ovae.state_dict(), strict=True)
+    for m in dunet.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    dunet.train()
+    return dunet, dvae.eval()
+
+
+def weight_checksum(unet, vae):
+    """Order-sensitive fp64 fingerprint of every parameter (frozen and LoRA) of both models."""
+    acc, k = 0.0, 1
+    for mod in (unet, vae):
+        for _, p in sorted(mod.named_parameters()):
+            v = p.detach().double().flatten()
+            acc += float(v.sum()) * (1.0 + 1e-3 * (k % 97)) + float(v[:: max(1, v.numel() // 64)].abs().sum()) * 1e-2
+            k += 1
+    return acc
+
+
+def oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=False):
+    """eps-MSE of train.py:793-834 and its gradients w.r.t. every LoRA factor, on the CPU in fp32.
+    `single_pass_doubled`: with a frozen text encoder the two passes of train.py:814-834 are identical computations, so
+    L = 2 L0 and g = 2 g0 exactly; evaluating one pass halves the host memory of the full-size C2 run."""
+    from oracle import scheduler
+    from oracle.fastconv import fast_temporal_conv3d
+    from oracle.train_step import finetune_unet_loss
+    from oracle.vae import tensor_to_vae_latent
+    for p in unet.parameters():
+        p.grad = None
+    with fast_temporal_conv3d():
+        if single_pass_doubled:
+            with torch.no_grad():
+                latents = tensor_to_vae_latent(batch["pixel_values"], vae, batch["vae_eps"])
+            noisy = scheduler.add_noise(latents, batch["noise"], batch["timesteps"], None)
+            pred = unet(noisy, batch["timesteps"], encoder_hidden_states=batch["encoder_hidden_states"]).sample
+            loss = 2.0 * torch.nn.functional.mse_loss(pred.float(), batch["noise"].float())
+        else:
+            loss, _ = finetune_unet_loss(unet, vae, batch)
+        loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in unet.named_parameters() if p.requires_grad}
+    return float(loss.detach()), grads
+
+
+def native_loss_and_grads(trainer, dunet, batch):
+    """One forward+backward of the native trainer (fused LoRA path, flat gradient buffer); gradients are read back through
+    each Parameter's `.grad` — a view of the flat buffer in the parameter's OWN layout, i.e. this un-permutes the
+    lora_bank storage plan (GEMM-layout down factors, transposed / block-diagonal up factors)."""
+    trainer.opt.zero_grad()
+    loss = trainer._fwd_bwd({k: v.cuda() for k, v in batch.items()})
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().float().cpu().clone() for n, p in dunet.named_parameters() if p.requires_grad}
+    return float(loss), grads
+
+
+def compare_grads(g_ref, g_dut, share=1e-3):
+    """(relative error of the whole gradient vector, its cosine, worst per-tensor relative error and worst per-tensor
+    cosine among tensors holding >= `share` of the gradient norm, number of such tensors)."""
+    num = den = dot = dd = 0.0
+    for n, a in g_ref.items():
+        a = a.double().flatten()
+        b = g_dut[n].double().flatten()
+        num += float((b - a).pow(2).sum()); den += float(a.pow(2).sum()); dot += float((a * b).sum()); dd += float(b.pow(2).sum())
+    worst_rel, worst_cos, counted = 0.0, 1.0, 0
+    for n, a in g_ref.items():
+        a = a.double().flatten()
+        b = g_dut[n].double().flatten()
+        na = float(a.pow(2).sum())
+        if na >= share * share * den and na > 0:
+            counted += 1
+            worst_rel = max(worst_rel, (float((b - a).pow(2).sum()) / na) ** 0.5)
+            worst_cos = min(worst_cos, float((a * b).sum()) / (na ** 0.5 * max(float(b.pow(2).sum()) ** 0.5, 1e-300)))
+    return dict(rel=(num / max(den, 1e-300)) ** 0.5, cos=dot / max((den * dd) ** 0.5, 1e-300), worst_rel=worst_rel,
+                worst_cos=worst_cos, tensors=counted)
+
+
+def fixture_path(config, scale):
+    return os.path.join(GOLDEN, f"oracle_step_{config}_s{scale:g}.pt")
+
+
+def sampled_names(names, every=12):
+    return sorted(names)[::every]

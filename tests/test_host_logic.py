@@ -61,11 +61,11 @@ def test_lora_handler_contract(tmp_path):
         if isinstance(mod, L._WRAPPERS):
             torch.nn.init.normal_(mod.lora_up.weight, std=0.05)
     h.save_lora_weights(m, str(tmp_path), step=7)
-    f = tmp_path / "7_unet.pt"
-    assert f.exists()
+    f = tmp_path / "lora" / "7_unet.pt"                      # utils/lora_handler.py:336: `{save_path}/lora/{step}_unet.pt`
+    assert f.exists() and not (tmp_path / "lora" / "7_text_encoder.pt").exists()
     m2 = _unet()
     h2 = LoraHandler(use_unet_lora=True)
-    h2.add_lora_to_model(True, m2, ["UNet3DConditionModel"], 0.0, str(tmp_path), r=4)
+    h2.add_lora_to_model(True, m2, ["UNet3DConditionModel"], 0.0, str(tmp_path / "lora"), r=4)
     a = dict(m.named_parameters()); b = dict(m2.named_parameters())
     assert all(torch.equal(a[n], b[n]) for n in a if "lora" in n)
     # collapse + remove restores a plain module tree with merged weights
@@ -161,7 +161,7 @@ def test_stable_lora_flavour_cpu_semantics(tmp_path):
     xl = torch.randn(3, 16)
     assert torch.allclose(lin(xl), TF.linear(xl, lin.weight + lin.lora_B @ lin.lora_A, lin.bias), atol=1e-6)
     m = _unet()
-    h = LoraHandler(version=LoraVersions.stable_lora, use_unet_lora=True)
+    h = LoraHandler(version=LoraVersions.stable_lora, use_unet_lora=True, save_for_webui=True)
     params, neg = h.add_lora_to_model(True, m, ["Transformer2DModel", "ResnetBlock2D"], 0.0, None, r=4)
     assert params is m and neg is None
     trainable = [n for n, p in m.named_parameters() if p.requires_grad]
@@ -169,10 +169,10 @@ def test_stable_lora_flavour_cpu_semantics(tmp_path):
     n_lora = sum(1 for x_ in m.modules() if isinstance(x_, SL._LORA_TYPES))
     assert n_lora == 271            # same layer count the reference cloneofsimo injector finds for this target list (golden)
     h.save_lora_weights(m, str(tmp_path), step=3)
-    f = tmp_path / "full_weights" / "3_lora_text_to_video_unet.safetensors"
+    f = tmp_path / "lora" / "full_weights" / "3_lora_text_to_video_unet.safetensors"
     assert f.exists()
     from safetensors.torch import load_file
-    web = load_file(str(tmp_path / "webui_3_lora_text_to_video.safetensors"))      # ModelScope key layout, fp16
+    web = load_file(str(tmp_path / "lora" / "webui_3_lora_text_to_video.safetensors"))      # ModelScope key layout, fp16
     assert len(web) == len(SL.lora_state_dict(m)) and all(v.dtype == torch.float16 for v in web.values())
     assert "input_blocks.1.1.transformer_blocks.0.attn1.to_q.lora_A" in web and "input_blocks.1.0.in_layers.2.lora_B" in web
     for x_ in m.modules():
@@ -355,3 +355,56 @@ def test_sampler_cfg_loop_with_a_stub_unet():
                                           generator=torch.Generator().manual_seed(2))
     assert out.shape == (1, 4, 2, 4, 4) and torch.allclose(out, x0, atol=1e-4)
     assert len(calls) == 6 and all(c[0] == 2 and c[2] == 2 for c in calls) and calls[0][1] == 999
+
+
+def test_vae_from_pretrained_accepts_a_full_diffusers_checkpoint(tmp_path):
+    """`AutoencoderKL.from_pretrained(path, subfolder="vae")` (the call in the reference's load_primary_models,
+    train.py:119-123) on a checkpoint in the stock diffusers layout: encoder + decoder + post_quant_conv, with the
+    ModelScope-era attention names query/key/value/proj_attn."""
+    import json
+    from safetensors.torch import save_file
+    from t2v_amd.models.vae import AutoencoderKL
+    cfg = dict(block_out_channels=(32, 64, 64, 64))
+    torch.manual_seed(0)
+    ref = AutoencoderKL(**cfg)
+    sd = {}
+    for k, v in ref.state_dict().items():
+        for a, b in ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn.")):
+            if ".attentions." in k:
+                k = k.replace(a, b)
+        sd[k] = v.clone()
+    assert any(".query." in k for k in sd)
+    sd["post_quant_conv.weight"] = torch.zeros(4, 4, 1, 1)
+    sd["post_quant_conv.bias"] = torch.zeros(4)
+    sd["decoder.conv_in.weight"] = torch.zeros(64, 4, 3, 3)
+    sd["decoder.mid_block.attentions.0.query.weight"] = torch.zeros(64, 64)
+    d = tmp_path / "vae"
+    d.mkdir()
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    with open(d / "config.json", "w") as f:
+        json.dump(dict(_class_name="AutoencoderKL", block_out_channels=list(cfg["block_out_channels"]), latent_channels=4), f)
+    m = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+    a, b = ref.state_dict(), m.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    # an unknown encoder-side key still fails loudly (the load stays strict)
+    sd["encoder.bogus.weight"] = torch.zeros(1)
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(RuntimeError):
+        AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+
+
+def test_ddim_leading_grid_of_the_modelscope_scheduler_config():
+    """`timestep_spacing="leading"`, `steps_offset=1`, `set_alpha_to_one=False` (ModelScope scheduler_config.json): the grid is
+    t_i = i*(T//n)+1, the step past the end uses abar_0, and an exact model stays on the trajectory."""
+    from t2v_amd.schedulers import DDIMScheduler
+    sch = DDIMScheduler(timestep_spacing="leading", steps_offset=1, set_alpha_to_one=False)
+    ts = sch.set_timesteps(50)
+    assert [int(t) for t in ts[:3]] == [981, 961, 941] and int(ts[-1]) == 1
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 2, 4, 4, generator=g, dtype=torch.float64)
+    eps = torch.randn(1, 4, 2, 4, 4, generator=g, dtype=torch.float64)
+    acp = sch.alphas_cumprod.double()
+    x = acp[ts[0]].sqrt() * x0 + (1 - acp[ts[0]]).sqrt() * eps
+    for t in ts:
+        x = sch.step((x - acp[t].sqrt() * x0) / (1 - acp[t]).sqrt(), t, x)
+    assert torch.allclose(x, acp[0].sqrt() * x0 + (1 - acp[0]).sqrt() * eps, atol=1e-9)   # final_alpha_cumprod = abar_0

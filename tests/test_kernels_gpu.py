@@ -411,3 +411,111 @@ def test_lora_branch_dropout_in_gemm_epilogue():
     y.backward(dy.cuda())
     assert relerr(y, yr) < TOL
     assert relerr(td.grad, tr.grad) < 3e-2 and relerr(wd.grad, wr.grad) < 3e-2
+
+
+@pytest.mark.parametrize("n,max_norm,world", [(100003, 1.0, 1), (4096, 0.05, 2), (777, 0.0, 1)])
+def test_sumsq_adamw_match_torch_optim(n, max_norm, world):
+    """t2v_sumsq + t2v_adamw against `clip_grad_norm_` + `torch.optim.AdamW` on IDENTICAL gradients (train.py:868-877:
+    global-norm clip 1.0, AdamW betas (0.9,0.999), wd 1e-2, eps 1e-8), several steps, incl. the 1/world pre-scale of a
+    SUM all-reduce and the no-clip case."""
+    import t2v_amd.native as nv
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-8, 1e-2
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([pr], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    p = p0.clone().cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda"); ss = torch.zeros(1, device="cuda")
+    for it in range(4):
+        grad = torch.randn(n, generator=g) * (10.0 if it == 1 else 0.01)       # one step far above the clip threshold
+        pr.grad = (grad / world).clone()
+        if max_norm > 0:
+            total = torch.nn.utils.clip_grad_norm_([pr], max_norm)
+        opt.step()
+        gd = grad.cuda()
+        ss.zero_()
+        if max_norm > 0:
+            nv.call("t2v_sumsq", gd.data_ptr(), n, ss.data_ptr(), nv.stream())
+            # the kernel clips the SCALED gradient: sumsq is taken after the all-reduce, before the 1/world scale
+            assert abs(ss.sqrt().item() / world - total.item()) < 1e-4 * total.item()
+        nv.call("t2v_adamw", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps, wd,
+                ss.data_ptr() if max_norm > 0 else None, max_norm, 1.0 / world, step.data_ptr(), nv.stream())
+        torch.cuda.synchronize()
+        assert step.item() == it + 1
+        upd_ref = (pr.detach() - p0).double()
+        upd = (p.cpu() - p0).double()
+        assert float((upd - upd_ref).norm() / upd_ref.norm()) < 1e-4, it
+    assert relerr(p, pr) < 1e-6
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_lora_wrappers_all_kinds_match_reference_golden(fused):
+    """All six layer kinds of tests/golden/lora_layers.pt (outputs of the REAL reference `utils/lora.py` Linear / Conv2d 3x3,
+    stride-2, 1x1 / Conv3d (3,1,1) wrappers) through the PRODUCT path: the drop-in wrapper modules evaluated by
+    `models.leaves.run_layer` — unfused (three launches) and fused (trainer bank attached: the path a train step takes)."""
+    import os
+    from t2v_amd.functional import ConvCfg, LINEAR
+    from t2v_amd.models.leaves import Tok, run_layer
+    from t2v_amd.training import FlatAdamW
+    from t2v_amd.utils import lora as L
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "lora_layers.pt"))
+    for name, it in gold.items():
+        st, x, r = it["state"], it["x"], it["r"]
+        if name.startswith("linear"):
+            w = st["linear.weight"]
+            mod = L.LoraInjectedLinear(w.shape[1], w.shape[0], bias="linear.bias" in st, r=r, dropout_p=0.0)
+        elif name == "conv3d":
+            w = st["conv.weight"]
+            mod = L.LoraInjectedConv3d(w.shape[1], w.shape[0], (3, 1, 1), (1, 0, 0), r=r, dropout_p=0.0)
+        else:
+            w = st["conv.weight"]
+            k = w.shape[2]
+            mod = L.LoraInjectedConv2d(w.shape[1], w.shape[0], k, 2 if name == "conv2d_s2" else 1, 1 if k == 3 else 0, r=r, dropout_p=0.0)
+        mod.load_state_dict(st, strict=True)
+        mod.scale = it["scale"]
+        mod = mod.cuda().train()
+        base = mod.linear if name.startswith("linear") else mod.conv
+        base.requires_grad_(False)
+        holder = torch.nn.Module(); holder.layer = mod
+        if fused:
+            FlatAdamW([mod.lora_down.weight, mod.lora_up.weight], model=holder)
+            assert getattr(mod, "_t2v_bank", None) is not None
+        xq = _bf(x)
+        if name.startswith("linear"):
+            xm, cfg = xq.reshape(-1, xq.shape[-1]).cuda(), LINEAR
+            ref = it["y"].reshape(-1, it["y"].shape[-1])
+        elif name == "conv3d":
+            B, C, Fr, H, W = xq.shape
+            xm = xq.permute(0, 2, 3, 4, 1).reshape(B * Fr * H * W, C).contiguous().cuda()
+            cfg = ConvCfg.conv3d_t(B, Fr, H * W)
+            ref = it["y"].permute(0, 2, 3, 4, 1).reshape(B * Fr * H * W, -1)
+        else:
+            n, C, H, W = xq.shape
+            xm = _cl(xq).cuda()
+            cfg = ConvCfg.conv2d(n, H, W, w.shape[2], 2 if name == "conv2d_s2" else 1, 1 if w.shape[2] == 3 else 0)
+            ref = _cl(it["y"])
+        xm.requires_grad_(True)
+        y = run_layer(mod, xm, cfg)
+        e = relerr(y[:, : ref.shape[1]].float(), ref)
+        assert e < 3e-2, (name, fused, e)
+        if fused:       # backward through the fused node: dx against autograd of the reference expression in fp32
+            import torch.nn.functional as TF2
+            dy = _bf(torch.randn(y.shape, generator=torch.Generator().manual_seed(1)))
+            y.backward(dy.cuda())
+            xr = xq.float().requires_grad_()
+            wd, wu = _bf(st["lora_down.weight"]).float(), _bf(st["lora_up.weight"]).float()
+            wb = _bf(w).float()
+            if name.startswith("linear"):
+                yr = TF2.linear(xr, wb) + TF2.linear(TF2.linear(xr, wd), wu) * it["scale"]
+                yr.reshape(-1, yr.shape[-1]).backward(dy[:, : yr.shape[-1]].float())
+                dxr = xr.grad.reshape(-1, xr.shape[-1])
+            elif name == "conv3d":
+                yr = TF2.conv3d(xr, wb, padding=(1, 0, 0)) + TF2.conv3d(TF2.conv3d(xr, wd, padding=(1, 0, 0)), wu) * it["scale"]
+                yr.permute(0, 2, 3, 4, 1).reshape(dy.shape[0], -1).backward(dy[:, : yr.shape[1]].float())
+                dxr = xr.grad.permute(0, 2, 3, 4, 1).reshape(xm.shape[0], -1)
+            else:
+                s_, p_ = (2 if name == "conv2d_s2" else 1), (1 if w.shape[2] == 3 else 0)
+                yr = TF2.conv2d(xr, wb, stride=s_, padding=p_) + TF2.conv2d(TF2.conv2d(xr, wd, stride=s_, padding=p_), wu) * it["scale"]
+                _cl(yr).backward(dy[:, : yr.shape[1]].float())
+                dxr = _cl(xr.grad)
+            assert relerr(xm.grad[:, : dxr.shape[1]].float(), dxr) < 3e-2, (name, "dx")

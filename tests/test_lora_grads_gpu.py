@@ -1,0 +1,215 @@
+"""Model-level parity of the FUSED LoRA path (GPU): eps-MSE and every LoRA factor gradient of the native trainer against the
+CPU fp32 oracle (autograd through utils/lora.py:57-62,134-139,211-216), toy config and full-size ModelScope-1.7B shapes.
+
+The native gradients are read through each Parameter's `.grad` (a view of the trainer's flat buffer in the parameter's own
+layout), so the lora_bank storage plan — GEMM-layout down factors, transposed / block-diagonal up factors, projection
+groups, side-stream factor-gradient launches — is checked against autograd, not against itself.
+
+Tolerances are anchored to the noise floor of the REFERENCE's own recipe: the same oracle under
+`torch.autocast(cpu, bfloat16)` vs fp32 (scripts/autocast_floor.py -> tests/golden/autocast_floor_*.json).  The native
+path stores activations in bf16 exactly like that recipe, so it is held to `FLOOR_FACTOR` x the recipe's own error (and the
+north-star 1e-3 on the loss wherever the recipe itself meets it).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import parity_utils as pu
+
+pytestmark = pytest.mark.gpu
+FLOOR_FACTOR = 2.0
+RESULTS = os.path.join(os.path.dirname(pu.GOLDEN), "..", "gpurun_out", "parity_r02.jsonl")
+
+
+def _floor(config, scale):
+    with open(os.path.join(pu.GOLDEN, f"autocast_floor_{config}.json")) as f:
+        rows = json.load(f)["rows"]
+    row = min(rows, key=lambda r: abs(r["lora_up_scale"] - scale))
+    return row
+
+
+def _record(**kw):
+    try:
+        os.makedirs(os.path.dirname(RESULTS), exist_ok=True)
+        with open(RESULTS, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+    print(json.dumps(kw))
+
+
+def _set_lora_up(ounet, dunet, scale):
+    from oracle.weights import randomize_lora_up
+    randomize_lora_up(ounet, scale=scale)
+    od = dict(ounet.named_parameters())
+    with torch.no_grad():
+        for n, p in dunet.named_parameters():
+            if p.requires_grad:
+                p.copy_(od[n])          # p.data is a view of the trainer's flat fp32 buffer
+
+
+# ------------------------------------------------------------------------------------------------ toy config, live oracle
+@pytest.fixture(scope="module")
+def toy():
+    from t2v_amd.training import DenoiseTrainer
+    ounet, ovae, n = pu.build_oracle(False, 4, 0.05)
+    dunet, dvae = pu.build_native(ounet, ovae, False, 4)
+    params = [p for p in dunet.parameters() if p.requires_grad]
+    return ounet, ovae, dunet, dvae, DenoiseTrainer(dunet, dvae, params, lr=1e-3)
+
+
+@pytest.mark.parametrize("scale", [0.0, 0.05, 0.2])
+def test_toy_lora_factor_gradients_match_oracle(toy, scale):
+    from oracle.weights import synthetic_batch
+    ounet, ovae, dunet, dvae, trainer = toy
+    _set_lora_up(ounet, dunet, scale)
+    batch = synthetic_batch(4, 64, 64, seed=100, text_dim=64)
+    lo, go = pu.oracle_loss_and_grads(ounet, ovae, batch)
+    ld, gd = pu.native_loss_and_grads(trainer, dunet, batch)
+    assert set(go) == set(gd)
+    c = pu.compare_grads(go, gd)
+    fl = _floor("toy", scale)
+    _record(test="toy_grads", scale=scale, loss_oracle=lo, loss_native=ld, loss_rel=abs(ld - lo) / abs(lo), floor_loss_rel=fl["loss_rel"],
+            floor_grad_rel=fl["grad_rel"], **c)
+    assert abs(ld - lo) / abs(lo) < 4e-3                      # toy clip: 64x fewer elements than C1 (see test_train_gpu.py)
+    assert c["rel"] < FLOOR_FACTOR * max(fl["grad_rel"], 0.1)
+    assert c["cos"] > 0.96
+    assert c["worst_cos"] > 0.6, "a LoRA factor gradient is decorrelated from autograd's: storage-plan / layout error"
+    assert c["tensors"] > 100
+
+
+def test_toy_optimizer_update_matches_oracle(toy):
+    """One full step (backward, global-norm clip, AdamW: train.py:861-879): compare the UPDATE p_after - p_before of every
+    LoRA factor, not the parameters (down ~ N(0,1/r) would dominate that norm).  AdamW's first step is
+    -lr * g / (|g| + eps): sign-like, so coordinates whose gradient is below the bf16 noise flip; the comparison is therefore
+    made on the coordinates that carry the update's signal (|g_oracle| above the per-tensor median) and via the cosine."""
+    from oracle.weights import synthetic_batch
+    ounet, ovae, dunet, dvae, trainer = toy
+    _set_lora_up(ounet, dunet, 0.05)
+    oparams = [p for p in ounet.parameters() if p.requires_grad]
+    oopt = torch.optim.AdamW(oparams, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    trainer.opt.exp_avg.zero_(); trainer.opt.exp_avg_sq.zero_(); trainer.opt.step_count.zero_()
+    before_o = {n: p.detach().clone() for n, p in ounet.named_parameters() if p.requires_grad}
+    before_d = {n: p.detach().float().cpu().clone() for n, p in dunet.named_parameters() if p.requires_grad}
+    batch = synthetic_batch(4, 64, 64, seed=100, text_dim=64)
+    lo, go = pu.oracle_loss_and_grads(ounet, ovae, batch)
+    torch.nn.utils.clip_grad_norm_(list(ounet.parameters()), 1.0)
+    oopt.step()
+    trainer.train_step({k: v.cuda() for k, v in batch.items()})
+    torch.cuda.synchronize()
+    od = dict(ounet.named_parameters())
+    num = den = dot = dd = 0.0
+    agree = total = 0
+    for n, p in dunet.named_parameters():
+        if not p.requires_grad:
+            continue
+        uo = (od[n].detach() - before_o[n]).double().flatten()
+        ud = (p.detach().float().cpu() - before_d[n]).double().flatten()
+        g = go[n].double().flatten().abs()
+        if float(g.max()) == 0.0:
+            continue
+        strong = g >= g.median()
+        agree += int((torch.sign(uo[strong]) == torch.sign(ud[strong])).sum()); total += int(strong.sum())
+        num += float((ud - uo).pow(2).sum()); den += float(uo.pow(2).sum()); dot += float((uo * ud).sum()); dd += float(ud.pow(2).sum())
+    rel, cos, sign = (num / den) ** 0.5, dot / (den * dd) ** 0.5, agree / max(total, 1)
+    _record(test="toy_update", update_rel=rel, update_cos=cos, sign_agreement_strong=sign)
+    assert cos > 0.9 and sign > 0.93, (rel, cos, sign)
+
+
+# ------------------------------------------------------------------------------------------------ full size, fixtures
+def _load_fixture(config, scale, ounet, ovae):
+    path = pu.fixture_path(config, scale)
+    if not os.path.exists(path):
+        return None
+    fx = torch.load(path, weights_only=False)
+    cs = pu.weight_checksum(ounet, ovae)
+    if abs(cs - fx["checksum"]) > 1e-6 * abs(fx["checksum"]):
+        print(f"[parity] fixture {os.path.basename(path)}: weight checksum differs ({cs} vs {fx['checksum']}); running the oracle live")
+        return None
+    return fx
+
+
+def _compare_with_fixture(fx, gd):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_step", os.path.join(pu.GOLDEN, "make_oracle_step.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    # (1) complete sketch: 4 random +-1 projections of every tensor
+    num = den = 0.0
+    worst_big = 0.0
+    gn2 = fx["grad_norm"] ** 2
+    for n, s_ref in fx["sketches"].items():
+        s_dut = mk.sketch(n, gd[n])
+        e = float((s_dut.double() - s_ref.double()).pow(2).sum())
+        num += e
+        den += float(s_ref.double().pow(2).sum())
+        nn2 = fx["grad_norms"][n] ** 2
+        if nn2 >= 1e-6 * gn2:                                   # E|proj|^2 = ||g||^2 per projection
+            worst_big = max(worst_big, (e / (mk.NPROJ * nn2)) ** 0.5)
+    sk_rel = (num / den) ** 0.5
+    # (2) norms of every tensor
+    bad_norm = [(n, float(gd[n].double().norm()), v) for n, v in fx["grad_norms"].items()
+                if v * v >= 1e-6 * gn2 and not (0.6 < float(gd[n].double().norm()) / v < 1.6)]
+    # (3) exact values of the sampled tensors
+    go = {n: v for n, v in fx["samples"].items()}
+    gs = {n: gd[n].flatten()[: v.numel()] for n, v in fx["samples"].items()}
+    c = pu.compare_grads(go, gs, share=0.0)
+    return sk_rel, worst_big, bad_norm, c
+
+
+def _full_case(config, scales):
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    frames, H, W, r = pu.CONFIGS[config]
+    ounet, ovae, n = pu.build_oracle(True, r, scales[0])
+    assert n == 574
+    dunet, dvae = pu.build_native(ounet, ovae, True, r)
+    trainer = DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=5e-6)
+    batch = synthetic_batch(frames, H, W, seed=1234)
+    out = []
+    for scale in scales:
+        _set_lora_up(ounet, dunet, scale)
+        fx = _load_fixture(config, scale, ounet, ovae)
+        ld, gd = pu.native_loss_and_grads(trainer, dunet, batch)
+        if fx is not None:
+            lo = fx["loss"]
+            sk_rel, worst_big, bad_norm, c = _compare_with_fixture(fx, gd)
+        else:
+            lo, go = pu.oracle_loss_and_grads(ounet, ovae, batch, single_pass_doubled=(config != "c1"))
+            c = pu.compare_grads(go, gd)
+            sk_rel, worst_big, bad_norm = c["rel"], c["worst_rel"], []
+        fl = _floor("c1", scale)
+        row = dict(test=f"full_{config}", scale=scale, loss_oracle=lo, loss_native=ld, loss_rel=abs(ld - lo) / abs(lo),
+                   grad_rel_sketch=sk_rel, worst_tensor_rel_sketch=worst_big, norm_outliers=len(bad_norm), sample_rel=c["rel"],
+                   sample_cos=c["cos"], sample_worst_cos=c["worst_cos"], floor_loss_rel=fl["loss_rel"], floor_grad_rel=fl["grad_rel"],
+                   fixture=fx is not None)
+        _record(**row)
+        out.append((row, bad_norm))
+    return out
+
+
+def _assert_case(row, bad_norm):
+    fl_loss, fl_grad = row["floor_loss_rel"], row["floor_grad_rel"]
+    assert row["loss_rel"] < max(1e-3, FLOOR_FACTOR * fl_loss), row       # north-star bar: 1e-3 (where the recipe itself meets it)
+    assert row["grad_rel_sketch"] < FLOOR_FACTOR * max(fl_grad, 0.05), row
+    assert row["worst_tensor_rel_sketch"] < 1.0, row                       # a decorrelated (mis-laid-out) tensor reads ~1.4
+    assert not bad_norm, bad_norm[:5]
+    assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row
+
+
+def test_full_c1_loss_and_lora_gradients():
+    """ModelScope-1.7B shapes, config C1 (8 frames @128x128, LoRA r=4): LoRA `up` amplitudes 0 (the reference's init,
+    utils/lora.py:55), 0.02 and 0.2 of N(0, 1/r); the N(0,1/r) point itself is reported, not asserted: there the network
+    leaves its trained regime (loss ~32) and the reference's OWN bf16 recipe has a gradient error of 5.75 (floor file)."""
+    rows = _full_case("c1", [0.0, 0.02, 0.2, 1.0])
+    for row, bad in rows[:3]:
+        _assert_case(row, bad)
+    assert rows[3][0]["loss_rel"] < 5e-2
+
+
+def test_full_c2_loss_and_lora_gradients():
+    """The configuration the metric is quoted on (BASELINE.json configs[1]): 16 frames @256x256, LoRA r=16."""
+    (row, bad), = _full_case("c2", [0.02])
+    _assert_case(row, bad)

@@ -74,6 +74,8 @@ def test_lora_train_steps_match_oracle():
     lr = 1e-3
     oopt = torch.optim.AdamW(oparams, lr=lr, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
     trainer = DenoiseTrainer(dunet, dvae, dparams, lr=lr)
+    before_o = {n: p.detach().clone() for n, p in ounet.named_parameters() if p.requires_grad}
+    before_d = {n: p.detach().float().cpu().clone() for n, p in dunet.named_parameters() if p.requires_grad}
     for step in range(2):
         batch = synthetic_batch(4, 64, 64, seed=100 + step, text_dim=64)
         lo, _ = oracle_step(ounet, ovae, batch, oopt)
@@ -83,13 +85,16 @@ def test_lora_train_steps_match_oracle():
         # north-star bar is 1e-3 on the full-size clip (65k latent elements, test_full_model_c1_loss_parity);
         # this toy clip averages over 64x fewer elements, so its bf16 sampling noise is ~8x larger
         assert rel < 4e-3
+    # compare the UPDATE p_after - p_before of the two optimisation steps (the parameters themselves are dominated by
+    # lora_down ~ N(0,1/r), which an entirely wrong update of ~lr per coordinate would not move measurably)
     od = dict(ounet.named_parameters())
-    errs = sorted(((relerr(p, od[n]), n) for n, p in dunet.named_parameters() if p.requires_grad), reverse=True)
-    print("worst LoRA params after 2 steps:", errs[:4])
-    flat_d = torch.cat([p.detach().flatten().cpu() for n, p in dunet.named_parameters() if p.requires_grad])
-    flat_o = torch.cat([od[n].detach().flatten() for n, p in dunet.named_parameters() if p.requires_grad])
-    # AdamW's first steps move every coordinate by ~lr*sign(g): compare the UPDATE direction on the coordinates that matter
-    assert relerr(flat_d, flat_o) < 5e-2
+    upd_d = torch.cat([(p.detach().float().cpu() - before_d[n]).flatten() for n, p in dunet.named_parameters() if p.requires_grad])
+    upd_o = torch.cat([(od[n].detach() - before_o[n]).flatten() for n, p in dunet.named_parameters() if p.requires_grad])
+    cos = float((upd_d.double() * upd_o.double()).sum() / (upd_d.double().norm() * upd_o.double().norm()))
+    print(f"two-step LoRA update: relerr {relerr(upd_d, upd_o):.3f} cosine {cos:.4f} |upd| {float(upd_o.norm()):.3e}")
+    # AdamW's first steps are sign-like (-lr g/|g|): coordinates whose gradient sits below the bf16 noise flip, so the bound
+    # is on the direction of the whole update (a wrong layout / missing factor gradient gives cosine ~0)
+    assert float(upd_o.norm()) > 0 and cos > 0.85
 
 
 def test_graph_replay_equals_eager():

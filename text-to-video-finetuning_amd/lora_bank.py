@@ -211,8 +211,9 @@ def attach(plans, flat_p16, flat_g, offsets):
 
 
 def is_homed(homes):
-    """True if the Parameters (first and last are enough: `Module._apply` moves all of them) still alias their flat-buffer views."""
-    for p, v, g in (homes[0], homes[-1]):
+    """True if EVERY Parameter still aliases its flat-buffer view (a partial move — `text_encoder.to(...)`, a sub-module
+    `.float()` — would otherwise detach parameters mid-list from the optimizer unnoticed; the check is ~1e3 pointer compares)."""
+    for p, v, g in homes:
         if p.data_ptr() != v.data_ptr() or p.grad is None or p.grad.data_ptr() != g.data_ptr():
             return False
     return True

@@ -48,6 +48,11 @@ class ModelMixinLite:
                 m.set_processor(processor)
 
     @classmethod
+    def _convert_checkpoint_keys(cls, sd):
+        """Hook: map a stock diffusers checkpoint onto this class's keys (identity by default; the load stays strict)."""
+        return sd
+
+    @classmethod
     def from_config(cls, config):
         cfg = config.to_dict() if hasattr(config, "to_dict") else dict(config)
         cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
@@ -80,6 +85,7 @@ class ModelMixinLite:
             sd = load_file(st)
         else:
             sd = torch.load(os.path.join(d, "diffusion_pytorch_model.bin"), map_location="cpu")
+        sd = cls._convert_checkpoint_keys(sd)     # per-class key filter / remap of stock diffusers checkpoints
         model.load_state_dict(sd, strict=True)
         if torch_dtype is not None:
             model.to(torch_dtype)

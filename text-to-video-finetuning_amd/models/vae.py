@@ -137,6 +137,23 @@ class AutoencoderKL(nn.Module, ModelMixinLite):
         self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
         self.use_slicing = False
 
+    @classmethod
+    def _convert_checkpoint_keys(cls, sd):
+        """A stock diffusers `vae/diffusion_pytorch_model.*` also carries the decoder half (`decoder.*`,
+        `post_quant_conv.*`), which the train step never uses (train.py:339-347 encodes only), and — in checkpoints of the
+        ModelScope era — the deprecated attention names `query/key/value/proj_attn`.  Drop the former, rename the latter;
+        the load itself stays strict on what remains."""
+        ren = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+        out = {}
+        for k, v in sd.items():
+            if k.startswith(("decoder.", "post_quant_conv.")):
+                continue
+            for a, b in ren.items():
+                if a in k and ".attentions." in k:
+                    k = k.replace(a, b)
+            out[k] = v
+        return out
+
     def enable_slicing(self):   # train.py:280,678 — batching knob only, results unchanged
         self.use_slicing = True
 

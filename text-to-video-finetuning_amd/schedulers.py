@@ -88,7 +88,34 @@ class _SamplerBase(DDPMScheduler):
 
 class DDIMScheduler(_SamplerBase):
     """Deterministic DDIM (eta = 0): x_prev = alpha_prev * x0 + sigma_prev * eps, with (x0, eps) recovered from the model
-    output at t.  Used by `inference.py` style sampling; exact along the true trajectory for an exact model."""
+    output at t.  Used by `inference.py` style sampling; exact along the true trajectory for an exact model.
+    `timestep_spacing="leading"`, `steps_offset=1`, `set_alpha_to_one=False` reproduce the grid of the ModelScope
+    `scheduler_config.json` (t_i = i * (T // n) + offset, previous step t - T // n, abar past the end = abar_0); the default
+    is the "linspace" grid shared with the DPM solver."""
+
+    def __init__(self, *args, timestep_spacing="linspace", steps_offset=0, set_alpha_to_one=True, **kw):
+        super().__init__(*args, **kw)
+        self.timestep_spacing, self.steps_offset, self.set_alpha_to_one = timestep_spacing, steps_offset, set_alpha_to_one
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        if self.timestep_spacing != "leading":
+            return super().set_timesteps(num_inference_steps, device)
+        ratio = self.num_train_timesteps // num_inference_steps
+        ts = (torch.arange(num_inference_steps) * ratio).flip(0).long() + self.steps_offset
+        self.timesteps = ts.to(device) if device is not None else ts
+        self.num_inference_steps, self._ratio = num_inference_steps, ratio
+        self._step_index, self._prev_x0, self._prev_lambda = 0, None, None
+        return self.timesteps
+
+    def _abar(self, t):
+        if t >= 0:
+            return self.alphas_cumprod[t].double()
+        return torch.tensor(1.0, dtype=torch.float64) if self.set_alpha_to_one else self.alphas_cumprod[0].double()
+
+    def _next_t(self):
+        if self.timestep_spacing == "leading":
+            return int(self.timesteps[self._step_index]) - self._ratio
+        return super()._next_t()
 
     def step(self, model_output, timestep, sample):
         t, tp = int(timestep), self._next_t()
@@ -101,8 +128,8 @@ class DDIMScheduler(_SamplerBase):
 
 
 class DPMSolverMultistepScheduler(_SamplerBase):
-    """DPM-Solver++(2M), data-prediction form, midpoint variant, first-order warm-up and first-order final step for short
-    schedules — the sampler the reference's validation uses (`DPMSolverMultistepScheduler.from_config`, train.py:923-926;
+    """DPM-Solver++(2M), data-prediction form, midpoint variant, first-order warm-up; the final step (sigma = 0) lands on the
+    data prediction — the sampler the reference's validation uses (`DPMSolverMultistepScheduler.from_config`, train.py:923-926;
     algorithm of Lu et al. 2022, eq. for the multistep second-order update):
         lambda_t = log(alpha_t / sigma_t), h = lambda_t - lambda_s
         first  : x_t = (sigma_t/sigma_s) x_s - alpha_t (e^{-h} - 1) D_s
@@ -126,8 +153,9 @@ class DPMSolverMultistepScheduler(_SamplerBase):
             h = lam_t - lam_s
             em1 = torch.expm1(-h)
             out = (s_t / s_s).to(sample.dtype) * sample - (a_t * em1).to(sample.dtype) * x0
-            second = (self.solver_order >= 2 and self._prev_x0 is not None
-                      and not (self.lower_order_final and self.num_inference_steps < 15 and self._step_index == len(self.timesteps) - 2))
+            # diffusers' `lower_order_final` (schedules < 15 steps) makes only the LAST step first order; with a final
+            # sigma of 0 that step already collapses onto the data prediction above, so every earlier step stays second order
+            second = self.solver_order >= 2 and self._prev_x0 is not None
             if second:
                 r0 = (lam_s - self._prev_lambda) / h
                 d1 = (x0 - self._prev_x0) / r0.to(sample.dtype)

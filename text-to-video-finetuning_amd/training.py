@@ -247,6 +247,14 @@ class DenoiseTrainer:
 
     # ---- HIP-graph replay of forward+backward (static shapes)
     def capture(self, batch, warmup=2):
+        # Dropout seeds are host-side counters passed to the kernels BY VALUE (models/leaves.py::_next_seed): a captured
+        # graph would replay the same masks every step.  Active dropout therefore runs eagerly (train_step).
+        active = [n for mod in (self.unet, self.text_encoder) if mod is not None for n, m in mod.named_modules()
+                  if isinstance(m, torch.nn.Dropout) and m.training and m.p > 0]
+        if active:
+            raise RuntimeError(f"DenoiseTrainer.capture(): {len(active)} active nn.Dropout modules (e.g. {active[0]}); a HIP graph "
+                               "would freeze their masks. Use train_step() (eager) with dropout on, or the reference's "
+                               "eval_train mode (train.py:779-781) for graph replay.")
         static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

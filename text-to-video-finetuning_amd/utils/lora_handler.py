@@ -67,7 +67,7 @@ class LoraHandler(object):
             import torch
             lora_file = self.get_lora_file_path(lora_path, model)
             activator = self.lora_injector(model, target_module=list(replace_modules),
-                                           search_class=[torch.nn.Linear, torch.nn.Conv2d, torch.nn.Conv3d], r=r, dropout=dropout,
+                                           search_class=[torch.nn.Linear, torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.Embedding], r=r, dropout=dropout,
                                            lora_bias=self.lora_bias)
             activator()
             if lora_file is not None:
@@ -82,17 +82,31 @@ class LoraHandler(object):
         return params, negation
 
     def deactivate_lora_train(self, models, deactivate=True):
-        return None   # cloneofsimo flavour: nothing to toggle (utils/lora_handler.py:271-277)
+        """utils/lora_handler.py:271-277: only the stable_lora flavour has a train/eval mode to toggle around sampling."""
+        if self.is_stable_lora():
+            from ..stable_lora.lora import set_mode_group
+            set_mode_group(models, not deactivate)
 
     def save_lora_weights(self, model, save_path="", step=""):
+        """utils/lora_handler.py:279-351: files go to `{save_path}/lora/`; cloneofsimo: `{step}_unet.pt` /
+        `{step}_text_encoder.pt`, each only if that LoRA is in use; stable_lora: `full_weights/` + `webui_` safetensors."""
+        save_path = os.path.join(save_path, "lora")
         os.makedirs(save_path, exist_ok=True)
         unet = getattr(model, "unet", model)
-        if self.is_stable_lora():
-            from ..stable_lora.lora import save_lora
-            save_lora(unet=unet, text_encoder=getattr(model, "text_encoder", None), save_text_weights=self.use_text_lora,
-                      output_dir=save_path, lora_filename=f"{step}_lora_text_to_video", lora_bias=self.lora_bias)
-            return
-        save_lora_weight(unet, os.path.join(save_path, f"{step}_unet.pt"), set(self.unet_replace_modules))
         te = getattr(model, "text_encoder", None)
-        if te is not None and self.use_text_lora:
+        if self.is_stable_lora():
+            import uuid
+            from ..stable_lora.lora import save_lora
+            name = "lora_text_to_video"
+            save_lora(unet=unet, text_encoder=te, save_text_weights=self.use_text_lora, output_dir=save_path,
+                      lora_filename=f"{step}_{name}", lora_bias=self.lora_bias, save_for_webui=self.save_for_webui,
+                      only_webui=self.only_for_webui,
+                      metadata={"stable_lora_text_to_video": "v1", "lora_name": name + "_" + uuid.uuid4().hex.lower()[:5]})
+            return
+        if any([self.save_for_webui, self.only_for_webui]):
+            import warnings
+            warnings.warn("'save_for_webui' is only supported by the stable_lora flavour (utils/lora_handler.py:340-346)")
+        if self.use_unet_lora and self.unet_replace_modules is not None:
+            save_lora_weight(unet, os.path.join(save_path, f"{step}_unet.pt"), set(self.unet_replace_modules))
+        if te is not None and self.use_text_lora and self.text_encoder_replace_modules is not None:
             save_lora_weight(te, os.path.join(save_path, f"{step}_text_encoder.pt"), set(self.text_encoder_replace_modules))
