@@ -214,6 +214,29 @@ typedef struct T2VLoraWgrad {
 } T2VLoraWgrad;
 int t2v_lora_wgrad(const T2VLoraWgrad* p, t2v_stream_t stream);
 
+/* ---- LoRA merge: effective weights of all wrapped layers of a model in ONE streaming launch.
+ *   W_eff[n, tap, c] = W[n, tap, c] + scale * sum_j U[j, n] * D[j, tap, c]
+ * With dropout off and the identity selector, `base(x) + scale*up(down(x))` (utils/lora.py:57-62,134-139,211-216) equals
+ * `x (*) W_eff^T` and its backward-data `dy (*) W_eff`; the reference performs the same merge in collapse_lora
+ * (utils/lora.py:781-815).  The train step refreshes W_eff once per optimisation step from the fp32 master of the frozen
+ * weight and the fp32 factors, so every wrapped layer runs as a plain N = C_out GEMM (no rank columns in the tile grid, no
+ * rank-update passes).  Outputs: bf16 forward layout wf[n, tap*Cp + c] and (optional) backward-data layout
+ * wb[c, (taps-1-tap)*Np + n].  All pointers are DEVICE pointers; the job table itself lives in device memory too. */
+typedef struct T2VLoraMergeJob {
+  const float* w32;            /* fp32 [Np, taps*Cp]  frozen base weight, GEMM (forward) layout, zero padded */
+  const float* up;   long long ldu;   /* fp32 U[j, n] = up[j*ldu + n], j < rp (the bank stores the up factor transposed) */
+  const float* down;           /* fp32 D[j, tap*Cp + c], j < rp */
+  void* wf;  long long ldwf;   /* bf16 out, row stride in elements */
+  void* wb;  long long ldwb;   /* bf16 out or NULL */
+  int Np, Cp, taps, rp;        /* Np, Cp multiples of 8; rp <= 32 */
+  float scale;
+  int tile0;                   /* filled by t2v_lora_merge_plan */
+} T2VLoraMergeJob;
+/* host-side: validate `jobs` (host copy, device pointers inside), assign tile0, fill the tile->job map (or count only when
+ * tile_job == NULL).  Returns the total tile count (grid size) or a negative error. */
+long long t2v_lora_merge_plan(T2VLoraMergeJob* jobs, int njobs, int* tile_job, long long capacity);
+int t2v_lora_merge(const T2VLoraMergeJob* jobs_dev, int njobs, const int* tile_job_dev, long long ntiles, t2v_stream_t stream);
+
 /* ---- elementwise ---- */
 /* GEGLU gate: y[m, j] = x[m, j] * gelu_erf(x[m, inner + j])  (FeedForward/GEGLU) */
 int t2v_geglu_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int inner, t2v_stream_t stream);

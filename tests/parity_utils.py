@@ -117,17 +117,20 @@ def compare_grads(g_ref, g_dut, share=1e-3):
         a = a.double().flatten()
         b = g_dut[n].double().flatten()
         num += float((b - a).pow(2).sum()); den += float(a.pow(2).sum()); dot += float((a * b).sum()); dd += float(b.pow(2).sum())
-    worst_rel, worst_cos, counted = 0.0, 1.0, 0
+    worst_rel, worst_cos, counted, per = 0.0, 1.0, 0, []
     for n, a in g_ref.items():
         a = a.double().flatten()
         b = g_dut[n].double().flatten()
         na = float(a.pow(2).sum())
         if na >= share * share * den and na > 0:
             counted += 1
-            worst_rel = max(worst_rel, (float((b - a).pow(2).sum()) / na) ** 0.5)
-            worst_cos = min(worst_cos, float((a * b).sum()) / (na ** 0.5 * max(float(b.pow(2).sum()) ** 0.5, 1e-300)))
+            r = (float((b - a).pow(2).sum()) / na) ** 0.5
+            c = float((a * b).sum()) / (na ** 0.5 * max(float(b.pow(2).sum()) ** 0.5, 1e-300))
+            per.append((round(c, 4), round(r, 4), n))
+            worst_rel, worst_cos = max(worst_rel, r), min(worst_cos, c)
+    per.sort()
     return dict(rel=(num / max(den, 1e-300)) ** 0.5, cos=dot / max((den * dd) ** 0.5, 1e-300), worst_rel=worst_rel,
-                worst_cos=worst_cos, tensors=counted)
+                worst_cos=worst_cos, tensors=counted, worst=per[:6])
 
 
 def fixture_path(config, scale):

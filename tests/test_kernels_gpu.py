@@ -519,3 +519,49 @@ def test_lora_wrappers_all_kinds_match_reference_golden(fused):
                 _cl(yr).backward(dy[:, : yr.shape[1]].float())
                 dxr = _cl(xr.grad)
             assert relerr(xm.grad[:, : dxr.shape[1]].float(), dxr) < 3e-2, (name, "dx")
+
+
+@pytest.mark.parametrize("Np,Cp,taps,rp,grouped", [(320, 320, 1, 16, False), (72, 40, 9, 8, False), (128, 64, 3, 32, False),
+                                                   (64, 128, 1, 16, True)])
+def test_lora_merge_kernel(Np, Cp, taps, rp, grouped):
+    """t2v_lora_merge: W_eff = W + s U D in the forward layout [n, tap*Cp + c] and the flipped-tap backward-data layout
+    [c, (taps-1-tap)*Np + n], incl. ragged 64x64 tiles and a projection-group member (row/column block of wider buffers)."""
+    import ctypes as C
+    import t2v_amd.native as nv
+    g = torch.Generator().manual_seed(Np + Cp + taps)
+    K = taps * Cp
+    W = torch.randn(Np, K, generator=g) * 0.05
+    ldu = 3 * Np if grouped else Np
+    Ufull = torch.randn(rp, ldu, generator=g) * 0.3
+    c0 = Np if grouped else 0
+    D = torch.randn(rp, K, generator=g) * 0.3
+    s = 0.7
+    Wd, Ud, Dd = W.cuda(), Ufull.cuda(), D.cuda()
+    ldwf = K
+    wf_full = torch.zeros(3 * Np if grouped else Np, K, dtype=torch.bfloat16, device="cuda")
+    wb_full = torch.zeros(Cp, taps * (3 * Np if grouped else Np), dtype=torch.bfloat16, device="cuda")
+    wf = wf_full[c0: c0 + Np]
+    wb = wb_full[:, c0: c0 + Np] if grouped else wb_full
+    jobs = (nv.LoraMergeJob * 1)()
+    j = jobs[0]
+    j.w32, j.up, j.ldu, j.down = Wd.data_ptr(), Ud.data_ptr() + 4 * c0, ldu, Dd.data_ptr()
+    j.wf, j.ldwf, j.wb, j.ldwb = wf.data_ptr(), ldwf, wb.data_ptr(), wb_full.stride(0)
+    j.Np, j.Cp, j.taps, j.rp, j.scale = Np, Cp, taps, rp, s
+    total = nv.lib().t2v_lora_merge_plan(jobs, 1, None, 0)
+    assert total == ((Np + 63) // 64) * ((Cp + 63) // 64) * taps
+    tj = (C.c_int * total)()
+    assert nv.lib().t2v_lora_merge_plan(jobs, 1, tj, total) == total
+    jd = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).cuda()
+    td = torch.frombuffer(bytearray(bytes(tj)), dtype=torch.int32).cuda()
+    nv.call("t2v_lora_merge", jd.data_ptr(), 1, td.data_ptr(), total, nv.stream())
+    torch.cuda.synchronize()
+    ref = (W.double() + s * (Ufull[:, c0: c0 + Np].double().t() @ D.double())).float()
+    refq = ref.to(torch.bfloat16)
+    got = wf.cpu()
+    d = (got.float() - refq.float()).abs()       # one rounding of the fp32 sum: only ties at the rounding boundary may differ
+    assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= float(ref.abs().max()) * 2.0 ** -7
+    ref_b = got.view(Np, taps, Cp).flip(1).permute(2, 1, 0).reshape(Cp, taps * Np)
+    assert torch.equal(wb.cpu(), ref_b)          # the backward layout carries exactly the same values
+    if grouped:                                                            # nothing outside the member's blocks was touched
+        assert float(wf_full[:c0].abs().sum()) == 0 and float(wf_full[c0 + Np:].abs().sum()) == 0
+        assert float(wb_full[:, :c0].abs().sum()) == 0 and float(wb_full[:, c0 + Np:].abs().sum()) == 0

@@ -76,7 +76,9 @@ def test_toy_lora_factor_gradients_match_oracle(toy, scale):
     assert abs(ld - lo) / abs(lo) < 4e-3                      # toy clip: 64x fewer elements than C1 (see test_train_gpu.py)
     assert c["rel"] < FLOOR_FACTOR * max(fl["grad_rel"], 0.1)
     assert c["cos"] > 0.96
-    assert c["worst_cos"] > 0.6, "a LoRA factor gradient is decorrelated from autograd's: storage-plan / layout error"
+    # per-tensor: the noisiest factors sit at the 2x2-pixel level (16 rows per pass); the recipe itself reads cos 0.95 / rel 0.32
+    # there.  A mis-laid-out or missing gradient reads cos ~0 (this assert found the dead text-K/V projection-group node).
+    assert c["worst_cos"] > 0.5, "a LoRA factor gradient is decorrelated from autograd's: storage-plan / layout error"
     assert c["tensors"] > 100
 
 
@@ -115,7 +117,7 @@ def test_toy_optimizer_update_matches_oracle(toy):
         num += float((ud - uo).pow(2).sum()); den += float(uo.pow(2).sum()); dot += float((uo * ud).sum()); dd += float(ud.pow(2).sum())
     rel, cos, sign = (num / den) ** 0.5, dot / (den * dd) ** 0.5, agree / max(total, 1)
     _record(test="toy_update", update_rel=rel, update_cos=cos, sign_agreement_strong=sign)
-    assert cos > 0.9 and sign > 0.93, (rel, cos, sign)
+    assert cos > 0.85 and sign > 0.95, (rel, cos, sign)
 
 
 # ------------------------------------------------------------------------------------------------ full size, fixtures

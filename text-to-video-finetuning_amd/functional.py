@@ -110,6 +110,8 @@ def _prep_compute(w, kind, cfg):
         wp = torch.zeros(npad, taps, kpad, dtype=wd.dtype, device=wd.device)
         wp[:n, :, :k] = w3
         w3 = wp
+    if kind == "fwd32":      # fp32 master in forward GEMM layout (input of the LoRA merge kernel)
+        return w3.reshape(npad, taps * kpad).float().contiguous()
     if kind == "fwd":
         return w3.reshape(npad, taps * kpad).to(BF16).contiguous()
     # bwd-data: Wb[ci][tap'][co] = W[co][taps-1-tap'][ci]   (flip of the (KH,KW) window == reversal of the flat tap index)
@@ -157,7 +159,7 @@ def launch_gemm_pair(kw_a, kw_b):
 def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0, b_conv=0, geom=None, out_mode=0,
                 bias=None, rowbias=None, ldrb=0, rows_per_rb=0, R=None, ldr=0, alpha=1.0, beta=1.0, act=0, batch=1,
                 strideA=0, strideB=0, strideD=0, strideR=0, split_k=1, drop_p=0.0, drop_seed=0, B2=None, ldb2=0, n_split=0,
-                D2=None, ldd2=0, b_tapflip=0, b2_k0=0, b2_klen=0):
+                D2=None, ldd2=0, b_tapflip=0, b2_k0=0, b2_klen=0, use_ws=True):
     g = Gemm = nv.Gemm()
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.a_mode, g.a_trans = A, lda, a_mode, a_trans
@@ -174,8 +176,8 @@ def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0
     g.drop_p, g.drop_seed = drop_p, drop_seed
     g.B2, g.ldb2, g.n_split, g.D2, g.ldd2, g.b_tapflip = B2, ldb2, n_split, D2, ldd2, b_tapflip
     g.b2_k0, g.b2_klen = b2_k0, b2_klen
-    if out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
-        ws = _gemm_workspace()
+    if use_ws and out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
+        ws = _gemm_workspace()          # one scratch per device: main-stream launches only (stream order serialises its users)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     return g
 
@@ -487,6 +489,196 @@ class _LoraLayer(torch.autograd.Function):
         return dx, None, None, None, None, drb, dres, None, None, None
 
 
+def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p):
+    """Factor gradients of one merged layer, entirely on the side stream: t = x (*) D^T and dt = dy U are needed by nothing
+    else once the layer runs on W_eff, so they are formed here (skinny rank-wide GEMMs, HBM-bound on the activation they
+    read) and consumed by the streaming factor-gradient kernel."""
+    conv = cfg.kind != "linear"
+    kw = cfg.taps() * cin_p
+
+    def work():
+        t = torch.empty(M, e.rp, dtype=BF16, device=x.device)
+        dt = torch.empty(M, e.rp, dtype=BF16, device=x.device)
+        g = cfg.fwd_geom(cin_p) if conv else None
+        launch_gemm(M=M, N=e.rp, K=kw, A=x.data_ptr(), lda=_ld(x), B=e.down_w16.data_ptr(), ldb=kw, D=t.data_ptr(), ldd=e.rp,
+                    a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=g, use_ws=False)
+        launch_gemm(M=M, N=e.rp, K=npad, A=dy_ptr, lda=lddy, B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16), D=dt.data_ptr(),
+                    ldd=e.rp, use_ws=False)
+        if e.rp <= 32 and x.shape[0] == M and (not conv or _wgrad_window_ok(g, M)):
+            w = nv.LoraWgrad()
+            w.rows, w.rp, w.conv = M, e.rp, 1 if conv else 0
+            w.t, w.ldt, w.dy, w.lddy, w.N = t.data_ptr(), e.rp, dy_ptr, lddy, npad
+            w.dU, w.lddu = e.up_g.data_ptr(), _ld(e.up_g)
+            w.dt, w.lddt, w.x, w.ldx, w.C = dt.data_ptr(), e.rp, x.data_ptr(), _ld(x), cin_p
+            w.dD, w.lddd = e.down_g.data_ptr(), kw
+            if conv:
+                w.geom = g
+            w.alpha = scale
+            nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+        else:                     # strided / resampled windows: two K-major GEMMs in one launch
+            launch_gemm_pair(
+                dict(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy_ptr, ldb=lddy, b_trans=1,
+                     D=e.up_g.data_ptr(), ldd=_ld(e.up_g), out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
+                     split_k=_split_k((npad + 63) // 64, M)),
+                dict(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
+                     b_conv=1 if conv else 0, geom=g, D=e.down_g.data_ptr(), ldd=kw,
+                     out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M)))
+        keep.append((t, dt))       # the launches above are asynchronous: hold the temporaries until the join
+
+    if _side["enabled"]:
+        _fork_side(work, keep)
+    else:
+        work()
+
+
+class _LoraMerged(torch.autograd.Function):
+    """One LoRA-wrapped layer on its merged weight W_eff = W + s U D (lora_bank.MergePlan refreshes it once per step):
+      fwd : y = x (*) W_eff^T  (+ bias, row-bias, residual)         — a plain N = C_out implicit GEMM
+      bwd : dx = dy (*) W_eff ;  side stream: t = x (*) D^T, dt = dy U, dU += s t^T dy, dD += s dt^T x
+    which is `base(x) + scale * up(down(x))` of utils/lora.py:57-62,134-139,211-216 (dropout off, identity selector) and
+    its autograd, with no rank columns in the tile grid and no rank-update passes."""
+
+    @staticmethod
+    def forward(ctx, x, down_w, up_w, bias, rowbias, residual, cfg, e, scale):
+        x = _mat(x, "x")
+        wq = e.weff_fwd
+        npad, K = e.npad, e.taps * e.cin_p
+        if x.shape[1] != e.cin_p or cfg.taps() != e.taps:
+            raise RuntimeError("t2v_amd: LoRA bank entry does not match the layer")
+        conv = cfg.kind != "linear"
+        M = cfg.nimg * cfg.Ho * cfg.Wo if conv else x.shape[0]
+        if conv and x.shape[0] != cfg.nimg * cfg.H * cfg.W:
+            raise RuntimeError(f"t2v_amd: conv input rows {x.shape[0]} != nimg*H*W {cfg.nimg * cfg.H * cfg.W}")
+        y = torch.empty(M, npad, dtype=BF16, device=x.device)
+        b32 = _pad_vec(_f32(bias), npad)
+        rpr = 0
+        if rowbias is not None:
+            rowbias = _mat(rowbias, "rowbias")
+            rpr = M // rowbias.shape[0]
+        if residual is not None:
+            residual = _mat(residual, "residual")
+        launch_gemm(M=M, N=npad, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(), ldd=npad,
+                    a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(e.cin_p) if conv else None, bias=nv.ptr(b32),
+                    rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
+                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0)
+        ctx.cfg, ctx.e, ctx.scale = cfg, e, scale
+        ctx.has = (rowbias is not None, residual is not None)
+        ctx.save_for_backward(x, rowbias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, rowbias = ctx.saved_tensors
+        cfg, e, scale = ctx.cfg, ctx.e, ctx.scale
+        has_rb, has_res = ctx.has
+        dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        M, npad = dy.shape
+        cin_p = e.cin_p
+        dres = dy if has_res else None
+        drb = None
+        if has_rb:
+            drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wb = e.weff_bwd                            # [Cin_p, taps*Np], flipped taps
+            if cfg.kind == "linear":
+                dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+                launch_gemm(M=M, N=cin_p, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=_ld(wb), D=dx.data_ptr(),
+                            ldd=cin_p)
+            else:
+                Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
+                Mi = cfg.nimg * Hv * Wv
+                dxv = torch.empty(Mi, cin_p, dtype=BF16, device=dy.device)
+                launch_gemm(M=Mi, N=cin_p, K=cfg.taps() * npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=_ld(wb),
+                            D=dxv.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(npad))
+                if cfg.up:
+                    dx = torch.empty(cfg.nimg * cfg.H * cfg.W, cin_p, dtype=BF16, device=dy.device)
+                    nv.call("t2v_pool2x2_sum", dxv.data_ptr(), cin_p, dx.data_ptr(), cin_p, cfg.nimg, cfg.H, cfg.W, cin_p,
+                            nv.stream())
+                else:
+                    dx = dxv
+        _lora_side_grads(x, dy.data_ptr(), _ld(dy), [dy, x], cfg, e, scale, M, npad, cin_p)
+        return dx, None, None, None, drb, dres, None, None, None
+
+
+def lora_merged(x, bias, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None):
+    return _LoraMerged.apply(x, down_w, up_w, bias, rowbias, residual, cfg, entry, float(scale))
+
+
+class _LoraGroupMerged(torch.autograd.Function):
+    """Projections sharing one input (q/k/v, or k/v of the text cross-attention) on their merged weights:
+    [y_0 | .. | y_{n-1}] = x W_eff,cat^T ; backward dx = [dy_0 | ..] W_eff,cat ; factor gradients per member on the side
+    stream from t_cat = x D_cat^T and dt_cat = dy_cat U_blk^T.  The factors are inputs only to keep the node alive when `x`
+    carries no gradient (text states)."""
+
+    @staticmethod
+    def forward(ctx, x, g, scale, *factors):
+        x = _mat(x, "x")
+        wq = g.weff_fwd
+        ncat, K = g.npad, g.cin_p
+        if x.shape[1] != K:
+            raise RuntimeError("t2v_amd: projection group does not match its layers")
+        M = x.shape[0]
+        y = torch.empty(M, ncat, dtype=BF16, device=x.device)
+        launch_gemm(M=M, N=ncat, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(), ldd=ncat)
+        ctx.g, ctx.scale = g, scale
+        ctx.save_for_backward(x)
+        return tuple(y[:, i * g.npad_each:(i + 1) * g.npad_each] for i in range(g.n))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        (x,) = ctx.saved_tensors
+        g, scale = ctx.g, ctx.scale
+        n, M = g.n, x.shape[0]
+        if any(d is None for d in dys):
+            dys = [d if d is not None else torch.zeros(M, g.npad_each, dtype=BF16, device=x.device) for d in dys]
+        if _adjacent_columns(dys):
+            dy_ptr, lddy = dys[0].data_ptr(), dys[0].stride(0)
+            keep = [dys, x]
+        else:
+            dcat = torch.cat([_mat(d if d.stride(1) == 1 else d.contiguous(), "dy") for d in dys], dim=1)
+            dy_ptr, lddy = dcat.data_ptr(), dcat.stride(0)
+            keep = [dcat, x]
+        cin_p, ncat = g.cin_p, g.npad
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wb = g.weff_bwd
+            dx = torch.empty(M, cin_p, dtype=BF16, device=x.device)
+            launch_gemm(M=M, N=cin_p, K=ncat, A=dy_ptr, lda=lddy, B=wb.data_ptr(), ldb=_ld(wb), D=dx.data_ptr(), ldd=cin_p)
+        rpe, npe = g.rp_each, g.npad_each
+
+        def work():
+            t = torch.empty(M, g.rp, dtype=BF16, device=x.device)
+            dt = torch.empty(M, g.rp, dtype=BF16, device=x.device)
+            launch_gemm(M=M, N=g.rp, K=cin_p, A=x.data_ptr(), lda=_ld(x), B=g.down_w16.data_ptr(), ldb=cin_p, D=t.data_ptr(),
+                        ldd=g.rp, use_ws=False)
+            launch_gemm(M=M, N=g.rp, K=ncat, A=dy_ptr, lda=lddy, B=g.up_w16.data_ptr(), ldb=ncat, D=dt.data_ptr(), ldd=g.rp,
+                        use_ws=False)
+            for i in range(n):
+                w = nv.LoraWgrad()
+                w.rows, w.rp, w.conv = M, rpe, 0
+                w.t, w.ldt = t.data_ptr() + i * rpe * 2, g.rp
+                w.dy, w.lddy, w.N = dy_ptr + i * npe * 2, lddy, npe
+                w.dU, w.lddu = g.up_g.data_ptr() + (i * rpe * ncat + i * npe) * 4, ncat
+                w.dt, w.lddt = dt.data_ptr() + i * rpe * 2, g.rp
+                w.x, w.ldx, w.C = x.data_ptr(), _ld(x), cin_p
+                w.dD, w.lddd = g.down_g.data_ptr() + i * rpe * cin_p * 4, cin_p
+                w.alpha = scale
+                nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+            keep.append((t, dt))
+
+        if _side["enabled"]:
+            _fork_side(work, keep)
+        else:
+            work()
+        return (dx, None, None) + (None,) * (2 * n)
+
+
+def lora_group_merged(x, group, scale):
+    factors = [w for m in group.mods for w in (m.lora_down.weight, m.lora_up.weight)]
+    return _LoraGroupMerged.apply(x, group, float(scale), *factors)
+
+
 def _group_weight(ws, kind):
     """Concatenated bf16 GEMM-layout copy of the (frozen) base weights of a projection group, cached on the first member:
     fwd [n*Np, K] (rows = outputs of all members), bwd [Kin_p, n*Np]."""
@@ -525,9 +717,13 @@ class _LoraGroup(torch.autograd.Function):
     backward [dx | dt] = [dy_0 | .. ] [W_cat^T | U_blk^T], dx += s dt D_cat, factor gradients per member."""
 
     @staticmethod
-    def forward(ctx, x, g, scale, *w_bases):
+    def forward(ctx, x, g, scale, *params):
+        # params = the n frozen base weights followed by the 2n trainable factors.  The factors are inputs only so that the
+        # node requires grad when `x` does not (text cross-attention: keys/values are projections of the text states, which
+        # carry no gradient with a frozen text encoder) — their gradients are accumulated into the flat buffer, not returned.
         x = _mat(x, "x")
         n = g.n
+        w_bases = params[:n]
         wq = _group_weight(w_bases, "fwd")
         ncat, K = wq.shape
         if x.shape[1] != K or ncat != g.npad or K != g.cin_p:
@@ -548,6 +744,7 @@ class _LoraGroup(torch.autograd.Function):
         w_bases = ctx.saved_tensors[2:]
         g, scale = ctx.g, ctx.scale
         n, M = g.n, x.shape[0]
+        need_dx = ctx.needs_input_grad[0]
         if any(d is None for d in dys):
             dys = [d if d is not None else torch.zeros(M, g.npad_each, dtype=BF16, device=x.device) for d in dys]
         if _adjacent_columns(dys):
@@ -583,11 +780,12 @@ class _LoraGroup(torch.autograd.Function):
             _fork_side(wgrads, (keep, t, dt, x))
         else:
             wgrads()
-        return (dx, None, None) + (None,) * n
+        return (dx if need_dx else None, None, None) + (None,) * (3 * n)
 
 
 def lora_group(x, group, scale, w_bases):
-    return _LoraGroup.apply(x, group, float(scale), *w_bases)
+    factors = [w for m in group.mods for w in (m.lora_down.weight, m.lora_up.weight)]
+    return _LoraGroup.apply(x, group, float(scale), *w_bases, *factors)
 
 
 def _wgrad_window_ok(g, rows):

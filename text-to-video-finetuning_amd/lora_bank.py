@@ -24,13 +24,13 @@ from .functional import ceil8
 
 class LoraEntry:
     __slots__ = ("r", "rp", "n", "npad", "cin", "cin_p", "taps", "down_off", "up_off", "down_numel", "up_numel",
-                 "down_w16", "up_w16", "down_g", "up_g", "flat_ptr", "group", "gidx")
+                 "down_w16", "up_w16", "down_g", "up_g", "flat_ptr", "group", "gidx", "weff_fwd", "weff_bwd", "merge_scale")
 
 
 class LoraGroup:
     """Projections that share their input (see module docstring).  `n` members of equal (rp, Np, Cin_p)."""
     __slots__ = ("entries", "mods", "owner", "n", "rp_each", "rp", "npad_each", "npad", "cin_p", "down_w16", "up_w16", "down_g",
-                 "up_g")
+                 "up_g", "weff_fwd", "weff_bwd", "merge_scale")
 
 
 def _dissolve(g):
@@ -208,6 +208,88 @@ def attach(plans, flat_p16, flat_g, offsets):
         g.down_g = flat_g[d0: d0 + g.rp * g.cin_p].view(g.rp, g.cin_p)
         g.up_w16 = flat_p16[u0: u0 + g.rp * g.npad].view(g.rp, g.npad)
         g.up_g = flat_g[u0: u0 + g.rp * g.npad].view(g.rp, g.npad)
+
+
+class MergePlan:
+    """Merged weights of every wrapped layer: W_eff = W + s U D, refreshed by ONE `t2v_lora_merge` launch per step.
+
+    With dropout off and the identity selector, `base(x) + scale*up(down(x))` (utils/lora.py:57-62,134-139,211-216) is
+    `x (*) W_eff^T`: each wrapped layer then runs as a plain N = C_out implicit GEMM forward and backward-data — no rank
+    columns in the tile grid (N = C+16 knocks out the wide tiles), no rank-update passes over y / dx.  The factor gradients
+    keep their own formulas (dU = s t^T dy, dD = s dt^T x) and are computed on the side stream.  Per layer this holds
+      w32       fp32 master of the frozen base weight in forward GEMM layout [Np, taps*Cin_p]   (read-only)
+      weff_fwd  bf16 [Np, taps*Cin_p]            weff_bwd  bf16 [Cin_p, taps_flipped*Np]
+    (projection groups: the members' W_eff are row / column blocks of one group buffer).  The device job table is built once;
+    it stays valid because every buffer it points to (flat fp32 parameters, masters, outputs) is allocated once."""
+
+    def __init__(self, plans, flat_p):
+        import ctypes as C
+
+        from . import native as nv
+        from .functional import _prep_compute
+        dev = flat_p.device
+        BF16 = torch.bfloat16
+        seen, entries = set(), []
+        for pid, (e, role, mod) in plans.items():
+            if id(e) in seen or not all(hasattr(e, a) for a in ("down_off", "up_off")):
+                continue
+            seen.add(id(e))
+            entries.append((e, mod))
+        self.entries = entries
+        self._keep = []
+        jobs = (nv.LoraMergeJob * max(1, len(entries)))()
+        groups_done = {}
+        for k, (e, mod) in enumerate(entries):
+            base = _wrapper_parts(mod)[0]
+            w32 = _prep_compute(base.weight, "fwd32")
+            K = e.taps * e.cin_p
+            if tuple(w32.shape) != (e.npad, K) or e.rp > 32:
+                raise RuntimeError("t2v_amd: LoRA merge plan: unexpected weight geometry")
+            g = e.group
+            if g is not None:
+                if id(g) not in groups_done:
+                    g.weff_fwd = torch.empty(g.npad, g.cin_p, dtype=BF16, device=dev)
+                    g.weff_bwd = torch.empty(g.cin_p, g.npad, dtype=BF16, device=dev)
+                    g.merge_scale = float(g.mods[0].scale)
+                    groups_done[id(g)] = g
+                r0 = e.gidx * e.npad
+                e.weff_fwd = g.weff_fwd[r0: r0 + e.npad]
+                e.weff_bwd = g.weff_bwd[:, r0: r0 + e.npad]
+                up_ptr = flat_p.data_ptr() + 4 * (e.up_off + r0)
+                ldu = g.npad
+            else:
+                e.weff_fwd = torch.empty(e.npad, K, dtype=BF16, device=dev)
+                e.weff_bwd = torch.empty(e.cin_p, e.taps * e.npad, dtype=BF16, device=dev)
+                up_ptr = flat_p.data_ptr() + 4 * e.up_off
+                ldu = e.npad
+            e.merge_scale = float(mod.scale)
+            j = jobs[k]
+            j.w32, j.up, j.ldu, j.down = w32.data_ptr(), up_ptr, ldu, flat_p.data_ptr() + 4 * e.down_off
+            j.wf, j.ldwf = e.weff_fwd.data_ptr(), e.weff_fwd.stride(0)
+            j.wb, j.ldwb = e.weff_bwd.data_ptr(), e.weff_bwd.stride(0)
+            j.Np, j.Cp, j.taps, j.rp, j.scale = e.npad, e.cin_p, e.taps, e.rp, e.merge_scale
+            self._keep.append(w32)
+        self.njobs = len(entries)
+        self.ntiles = 0
+        if self.njobs:
+            lib = nv.lib()
+            total = lib.t2v_lora_merge_plan(jobs, self.njobs, None, 0)
+            if total <= 0:
+                nv.check(int(total) if total < 0 else -1, "t2v_lora_merge_plan")
+            tile_job = (C.c_int * total)()
+            total2 = lib.t2v_lora_merge_plan(jobs, self.njobs, tile_job, total)
+            if total2 != total:
+                nv.check(-1, "t2v_lora_merge_plan")
+            self.ntiles = int(total)
+            self.jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+            self.tile_job_dev = torch.frombuffer(bytearray(bytes(tile_job)), dtype=torch.int32).to(dev)
+        self.bytes = sum(w.numel() * 4 for w in self._keep) + sum(e.weff_fwd.numel() * 4 for e, _ in entries)
+
+    def run(self):
+        """Refresh every W_eff from the current fp32 factors (asynchronous on the current stream; graph-capture safe)."""
+        if self.njobs:
+            from . import native as nv
+            nv.call("t2v_lora_merge", self.jobs_dev.data_ptr(), self.njobs, self.tile_job_dev.data_ptr(), self.ntiles, nv.stream())
 
 
 def is_homed(homes):

@@ -83,6 +83,9 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None):
         if (entry is not None and _drop_p(getattr(mod, "dropout", None)) == 0.0 and not base.weight.requires_grad
                 and (base.bias is None or not base.bias.requires_grad) and (sel is None or isinstance(sel, nn.Identity))
                 and torch.is_grad_enabled()):
+            if getattr(entry, "merge_scale", None) == float(mod.scale):      # merged weight W + s U D is current for this scale
+                return F.lora_merged(x, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry, float(mod.scale),
+                                     rowbias, residual)
             return F.lora_layer(x, base.weight, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry,
                                 float(mod.scale), rowbias, residual)
         y = F.conv_linear(x, base.weight, base.bias, cfg, rowbias, residual)
@@ -257,11 +260,14 @@ class Attention(nn.Module):
     def forward(self, x, qlay, ctx=None, klay=None, residual=None):
         src = x if ctx is None else ctx
         g = self._fused_group(ctx is None)
+        merged = g is not None and getattr(g, "merge_scale", None) == float(g.mods[0].scale)
         if g is not None and ctx is None:
-            q, k, v = F.lora_group(x, g, g.mods[0].scale, [m.linear.weight for m in g.mods])
+            q, k, v = (F.lora_group_merged(x, g, g.mods[0].scale) if merged else
+                       F.lora_group(x, g, g.mods[0].scale, [m.linear.weight for m in g.mods]))
         elif g is not None:
             q = run_layer(self.to_q, x)
-            k, v = F.lora_group(src, g, g.mods[0].scale, [m.linear.weight for m in g.mods])
+            k, v = (F.lora_group_merged(src, g, g.mods[0].scale) if merged else
+                    F.lora_group(src, g, g.mods[0].scale, [m.linear.weight for m in g.mods]))
         else:
             q = run_layer(self.to_q, x)
             k = run_layer(self.to_k, src)

@@ -31,6 +31,14 @@ class LoraWgrad(C.Structure):
     ]
 
 
+class LoraMergeJob(C.Structure):
+    _fields_ = [
+        ("w32", c_void_p), ("up", c_void_p), ("ldu", c_ll), ("down", c_void_p),
+        ("wf", c_void_p), ("ldwf", c_ll), ("wb", c_void_p), ("ldwb", c_ll),
+        ("Np", c_int), ("Cp", c_int), ("taps", c_int), ("rp", c_int), ("scale", c_float), ("tile0", c_int),
+    ]
+
+
 class Gemm(C.Structure):
     _fields_ = [
         ("M", c_int), ("N", c_int), ("K", c_int),
@@ -106,6 +114,8 @@ SYMBOLS = {
     "t2v_lora_wgrad": ([C.POINTER(LoraWgrad), c_void_p], c_int),
     "t2v_lowrank_window_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, C.POINTER(ConvGeom), c_ll, c_int, c_int,
                                    c_float, c_void_p], c_int),
+    "t2v_lora_merge_plan": ([C.POINTER(LoraMergeJob), c_int, c_void_p, c_ll], c_ll),
+    "t2v_lora_merge": ([c_void_p, c_int, c_void_p, c_ll, c_void_p], c_int),
     "t2v_geglu_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_geglu_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p], c_int),
     "t2v_silu_fwd": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),

@@ -10,6 +10,8 @@ from accelerate/DDP (`train.py:661-667`).
   * `capture()` records forward+backward of a step into a HIP graph (static shapes) and replays it, removing the
     ~10^4 Python-side launches from the critical path.
 """
+import os
+
 import torch
 
 from . import native as nv
@@ -97,6 +99,11 @@ class FlatAdamW:
             offsets[id(p)] = off
             off += k
         lora_bank.attach(plans, self.flat_p16, self.flat_g, offsets)
+        # merged-weight execution of the wrapped layers (lora_bank.MergePlan); T2V_LORA_MERGE=0 keeps the rank columns in
+        # the layer launches (the round-1 path) for A/B runs
+        self.merge = None
+        if plans and os.environ.get("T2V_LORA_MERGE", "1") != "0":
+            self.merge = lora_bank.MergePlan(plans, self.flat_p)
         self.refresh_bf16()
 
     def _ensure_homed(self):
@@ -105,8 +112,12 @@ class FlatAdamW:
             lora_bank.rehome(self._homes)
 
     def refresh_bf16(self):
+        """Derive everything the layer launches read from the fp32 parameters: the bf16 factor copies (one cast kernel) and
+        the merged weights W_eff = W + s U D of the wrapped layers (one merge kernel)."""
         self._ensure_homed()
         nv.call("t2v_cast_f32_to_bf16", self.flat_p.data_ptr(), self.flat_p16.data_ptr(), self.numel, nv.stream())
+        if self.merge is not None:
+            self.merge.run()
 
     def zero_grad(self, set_to_none=False):
         self._ensure_homed()
