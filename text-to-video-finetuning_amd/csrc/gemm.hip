@@ -739,6 +739,10 @@ struct DmaCfg {
 int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
   T2VGemm q = p;
   int split = c.split;
+  // a cached / pinned configuration may ask for split-K while THIS launch brings no (or too small a) scratch buffer
+  if (split > 1 && (!p.workspace || p.batch > 1 || p.out_mode != T2V_OUT_BF16 ||
+                    (size_t)p.M * p.N * 4 * (size_t)split + 16 > p.workspace_bytes))
+    split = 1;
   if (split > 1) {
     const int per = ((p.K + split - 1) / split + BK - 1) / BK * BK;
     split = (p.K + per - 1) / per;              // every split slice is written (no empty K ranges)

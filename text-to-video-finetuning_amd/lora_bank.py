@@ -241,7 +241,7 @@ class MergePlan:
         groups_done = {}
         for k, (e, mod) in enumerate(entries):
             base = _wrapper_parts(mod)[0]
-            w32 = _prep_compute(base.weight, "fwd32")
+            w32 = _prep_compute(base.weight, "fwd32", None)
             K = e.taps * e.cin_p
             if tuple(w32.shape) != (e.npad, K) or e.rp > 32:
                 raise RuntimeError("t2v_amd: LoRA merge plan: unexpected weight geometry")
