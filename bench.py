@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-text-encoder", action="store_true", help="feed synthetic text states instead of running CLIP")
+    ap.add_argument("--export-tune-table", default=None,
+                    help="write the GEMM tile table after the run (use with T2V_GEMM_AUTOTUNE=live; scripts/tune_gemm_table.sh)")
     return ap.parse_args()
 
 
@@ -362,6 +364,10 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    if args.export_tune_table and rank == 0:
+        import t2v_amd.native as nv
+        print(f"[bench] exported {nv.export_tune_table(args.export_tune_table)} tile-table entries to {args.export_tune_table}",
+              file=sys.stderr)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -6,9 +6,9 @@
  * that one reference call site dispatches to (cited per function).  Conventions:
  *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer;
  *   - asynchronous on the given hipStream_t, no internal synchronisation, no allocation
- *     (graph-capture safe); caller owns all memory incl. workspaces.  One exception, outside stream
- *     capture only: the FIRST t2v_gemm call of a problem signature times its tile candidates
- *     (device synchronisation + HIP events, a few ms; T2V_GEMM_AUTOTUNE=0 selects tiles heuristically);
+ *     (graph-capture safe); caller owns all memory incl. workspaces.  t2v_gemm picks its tile from a shipped table
+ *     (t2v_gemm_tune_import) or a heuristic and never synchronises; only a TUNING run (T2V_GEMM_AUTOTUNE=live) times
+ *     candidates of unknown signatures on first use, to produce that table (t2v_gemm_tune_export);
  *   - returns 0 on success, negative T2V_E* on error; t2v_last_error() gives a thread-local text;
  *   - activations are "token matrices": row-major [rows, ld] bf16, channels contiguous
  *     (channels-last).  rows = images*H*W.  `ld` = row stride in ELEMENTS;
@@ -102,6 +102,11 @@ typedef struct {
   void* workspace; size_t workspace_bytes; int ws_split;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
+/* Tuned tile table: text, one line per problem signature ("M N K a_mode n_split out_mode has_res batch KH KW sy tdiv up C
+ * tile stages split").  export: writes at most `cap` bytes (NUL-terminated) and returns the size needed; import: merges the
+ * lines into the table and returns the number of entries accepted. */
+long long t2v_gemm_tune_export(char* buf, long long cap);
+int t2v_gemm_tune_import(const char* text);
 /* Two independent K-major problems (a_trans = b_trans = 1, fp32 atomic output) in ONE launch: the two LoRA factor
  * gradients dU = s t^T dy and dD = s dt^T x_col of a wrapped layer (backward of utils/lora.py:57-62). */
 int t2v_gemm_pair(const T2VGemm* a, const T2VGemm* b, t2v_stream_t stream);

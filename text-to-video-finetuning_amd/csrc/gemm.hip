@@ -816,26 +816,38 @@ std::unordered_map<TuneKey, DmaCfg, TuneHash> g_tuned;
 std::mutex g_tune_mu;
 int g_autotune = -1;
 
+TuneKey make_key(const T2VGemm& p) {
+  TuneKey key;
+  memset(&key, 0, sizeof(key));
+  key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = p.n_split > 0; key.out_mode = p.out_mode;
+  key.has_res = p.R != nullptr; key.batch = p.batch > 1 ? p.batch : 1;
+  if (p.a_mode == T2V_A_CONV) { key.KH = p.geom.KH; key.KW = p.geom.KW; key.sy = p.geom.sy; key.tdiv = p.geom.tdiv; key.up = p.geom.up; key.C = p.geom.C; }
+  return key;
+}
+
+// Tile selection.  T2V_GEMM_AUTOTUNE:
+//   unset / "table" : the shipped table (t2v_gemm_tune_import, loaded by the host binding from gemm_tune_gfx950.txt), else the
+//                     heuristic — NEVER synchronises, every call is asynchronous on the caller's stream (ABI contract);
+//   "live"          : unknown signatures are timed on first use (device synchronisation + HIP events; tuning runs only —
+//                     scripts/tune_gemm_table.py exports the result as the shipped table);
+//   "0"             : heuristic only.
 DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   if (g_autotune < 0) {
     const char* e = getenv("T2V_GEMM_AUTOTUNE");
-    g_autotune = (e && e[0] == '0') ? 0 : 1;
+    g_autotune = !e ? 1 : (e[0] == '0' ? 0 : ((e[0] == 'l' || e[0] == '2') ? 2 : 1));
   }
   if (!g_autotune) return heuristic_cfg(p);
   if (const char* f = getenv("T2V_GEMM_FORCE_CFG")) {       // "tile,stages,split": pin one configuration (counter passes, A/B runs)
     int t = 0, st = 2, sp = 1;
     if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && t >= 0 && t <= 9) return DmaCfg{t, st, sp < 1 ? 1 : sp};
   }
-  TuneKey key;
-  memset(&key, 0, sizeof(key));
-  key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = p.n_split > 0; key.out_mode = p.out_mode;
-  key.has_res = p.R != nullptr; key.batch = p.batch > 1 ? p.batch : 1;
-  if (p.a_mode == T2V_A_CONV) { key.KH = p.geom.KH; key.KW = p.geom.KW; key.sy = p.geom.sy; key.tdiv = p.geom.tdiv; key.up = p.geom.up; key.C = p.geom.C; }
+  const TuneKey key = make_key(p);
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) return it->second;
   }
+  if (g_autotune != 2) return heuristic_cfg(p);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return heuristic_cfg(p);
   // candidates
@@ -1007,6 +1019,48 @@ int check_gemm(const T2VGemm& p) {
   return T2V_OK;
 }
 }  // namespace
+
+// ---- tuned-table transport: one text line per problem signature
+//   M N K a_mode n_split out_mode has_res batch KH KW sy tdiv up C  tile stages split
+extern "C" long long t2v_gemm_tune_export(char* buf, long long cap) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  long long need = 0;
+  for (const auto& kv : g_tuned) {
+    char line[256];
+    const TuneKey& k = kv.first;
+    int n = snprintf(line, sizeof(line), "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", k.M, k.N, k.K, k.a_mode, k.n_split,
+                     k.out_mode, k.has_res, k.batch, k.KH, k.KW, k.sy, k.tdiv, k.up, k.C, kv.second.tile, kv.second.stages,
+                     kv.second.split);
+    if (buf && need + n < cap) memcpy(buf + need, line, (size_t)n);
+    need += n;
+  }
+  if (buf && need < cap) buf[need] = 0;
+  return need + 1;
+}
+
+extern "C" int t2v_gemm_tune_import(const char* text) {
+  T2V_CHECK_ARG(text != nullptr, "t2v_gemm_tune_import: null text");
+  int count = 0;
+  const char* p = text;
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  while (*p) {
+    TuneKey k;
+    memset(&k, 0, sizeof(k));
+    DmaCfg c{0, 2, 1};
+    int consumed = 0;
+    if (sscanf(p, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d%n", &k.M, &k.N, &k.K, &k.a_mode, &k.n_split, &k.out_mode,
+               &k.has_res, &k.batch, &k.KH, &k.KW, &k.sy, &k.tdiv, &k.up, &k.C, &c.tile, &c.stages, &c.split, &consumed) == 17) {
+      if (c.tile >= 0 && c.tile <= 9 && (c.stages == 0 || c.stages == 2) && c.split >= 1 && c.split <= 64) {
+        g_tuned[k] = c;
+        ++count;
+      }
+      p += consumed;
+    }
+    while (*p && *p != '\n') ++p;
+    if (*p == '\n') ++p;
+  }
+  return count;
+}
 
 extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
   T2V_CHECK_ARG(pp != nullptr, "t2v_gemm: null descriptor");

@@ -13,6 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2v_hip.so")
+TUNE_TABLE = os.path.join(_HERE, "gemm_tune_gfx950.txt")
 
 c_void_p, c_int, c_ll, c_float, c_ull = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
 
@@ -92,6 +93,8 @@ SYMBOLS = {
     "t2v_abi_version": ([], c_int),
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_gemm_tune_export": ([C.c_char_p, c_ll], c_ll),
+    "t2v_gemm_tune_import": ([C.c_char_p], c_int),
     "t2v_gemm_pair": ([C.POINTER(Gemm), C.POINTER(Gemm), c_void_p], c_int),
     "t2v_smallconv": ([C.POINTER(SmallConv), c_void_p], c_int),
     "t2v_gn_workspace_floats": ([c_int, c_int], c_ll),
@@ -152,7 +155,22 @@ def lib():
         if l.t2v_abi_version() != 1:
             raise RuntimeError("t2v_amd: ABI version mismatch")
         _lib = l
+        if os.path.exists(TUNE_TABLE) and os.environ.get("T2V_GEMM_TABLE", "1") != "0":
+            with open(TUNE_TABLE, "rb") as f:       # shipped tile table: t2v_gemm never times candidates at run time
+                l.t2v_gemm_tune_import(f.read())
     return _lib
+
+
+def export_tune_table(path=None):
+    """Write the library's current tile table (shipped entries + whatever a T2V_GEMM_AUTOTUNE=live run added)."""
+    l = lib()
+    need = l.t2v_gemm_tune_export(None, 0)
+    buf = C.create_string_buffer(int(need))
+    l.t2v_gemm_tune_export(buf, need)
+    lines = sorted(set(buf.value.decode().splitlines()), key=lambda s: [int(x) for x in s.split()])
+    with open(path or TUNE_TABLE, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return len(lines)
 
 
 def stream():

@@ -179,9 +179,7 @@ class DenoiseTrainer:
             ids = batch["prompt_ids"]                # VAE encode, so it runs on an auxiliary stream beside it
             if ids.dim() > 2:
                 ids = ids[0]
-            if self._aux_stream is None:
-                self._aux_stream = torch.cuda.Stream()
-            aux = self._aux_stream
+            aux = self._aux()
             aux.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(aux), torch.no_grad():
                 ehs = self.text_encoder(ids)[0]
@@ -196,9 +194,9 @@ class DenoiseTrainer:
         else:
             timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bsz,), device=latents.device).long()
         noisy = self.scheduler.add_noise(latents, noise, timesteps)
-        if aux is not None:
-            torch.cuda.current_stream().wait_stream(aux)
-        elif ehs is None:
+        if self._aux_stream is not None:             # CLIP and/or the parameter refresh of _fwd_bwd ran beside the VAE encode
+            torch.cuda.current_stream().wait_stream(self._aux_stream)
+        if ehs is None:
             ehs = batch["encoder_hidden_states"]
         if self.scheduler.prediction_type == "epsilon":
             target = noise
@@ -237,8 +235,18 @@ class DenoiseTrainer:
             noise = noise + self.offset_noise_strength * torch.randn(b, c, f, 1, 1, device=latents.device)
         return noise
 
+    def _aux(self):
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream()
+        return self._aux_stream
+
     def _fwd_bwd(self, batch):
-        self.opt.refresh_bf16()            # bf16 copies of every LoRA factor for this step: one cast kernel
+        # bf16 factor copies + merged weights W_eff for this step (one cast + one merge kernel, HBM-bound): on the auxiliary
+        # stream, beside the MFMA-bound VAE encode; loss_fn joins it before the UNet
+        aux = self._aux()
+        aux.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(aux):
+            self.opt.refresh_bf16()
         loss = self.loss_fn(batch)
         loss.backward()
         from .functional import join_side_stream
