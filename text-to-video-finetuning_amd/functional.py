@@ -489,27 +489,31 @@ class _LoraLayer(torch.autograd.Function):
         return dx, None, None, None, None, drb, dres, None, None, None
 
 
-def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p):
-    """Factor gradients of one merged layer, entirely on the side stream: t = x (*) D^T and dt = dy U are needed by nothing
-    else once the layer runs on W_eff, so they are formed here (skinny rank-wide GEMMs, HBM-bound on the activation they
-    read) and consumed by the streaming factor-gradient kernel."""
+def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=None, dt=None):
+    """Factor gradients of one merged layer on the side stream: dU += s t^T dy, dD += s dt^T x (streaming kernel; strided /
+    resampled windows: two K-major GEMMs in one launch).  `t = x (*) D^T` normally rides in the forward launch and
+    `dt = dy U` in the backward-data launch (rank columns of those launches); whichever is missing is formed here by a
+    skinny rank-wide GEMM."""
     conv = cfg.kind != "linear"
     kw = cfg.taps() * cin_p
 
     def work():
-        t = torch.empty(M, e.rp, dtype=BF16, device=x.device)
-        dt = torch.empty(M, e.rp, dtype=BF16, device=x.device)
+        tt, dtt = t, dt
         g = cfg.fwd_geom(cin_p) if conv else None
-        launch_gemm(M=M, N=e.rp, K=kw, A=x.data_ptr(), lda=_ld(x), B=e.down_w16.data_ptr(), ldb=kw, D=t.data_ptr(), ldd=e.rp,
-                    a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=g, use_ws=False)
-        launch_gemm(M=M, N=e.rp, K=npad, A=dy_ptr, lda=lddy, B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16), D=dt.data_ptr(),
-                    ldd=e.rp, use_ws=False)
+        if tt is None:
+            tt = torch.empty(M, e.rp, dtype=BF16, device=x.device)
+            launch_gemm(M=M, N=e.rp, K=kw, A=x.data_ptr(), lda=_ld(x), B=e.down_w16.data_ptr(), ldb=kw, D=tt.data_ptr(),
+                        ldd=e.rp, a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=g, use_ws=False)
+        if dtt is None:
+            dtt = torch.empty(M, e.rp, dtype=BF16, device=x.device)
+            launch_gemm(M=M, N=e.rp, K=npad, A=dy_ptr, lda=lddy, B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16), D=dtt.data_ptr(),
+                        ldd=e.rp, use_ws=False)
         if e.rp <= 32 and x.shape[0] == M and (not conv or _wgrad_window_ok(g, M)):
             w = nv.LoraWgrad()
             w.rows, w.rp, w.conv = M, e.rp, 1 if conv else 0
-            w.t, w.ldt, w.dy, w.lddy, w.N = t.data_ptr(), e.rp, dy_ptr, lddy, npad
+            w.t, w.ldt, w.dy, w.lddy, w.N = tt.data_ptr(), _ld(tt), dy_ptr, lddy, npad
             w.dU, w.lddu = e.up_g.data_ptr(), _ld(e.up_g)
-            w.dt, w.lddt, w.x, w.ldx, w.C = dt.data_ptr(), e.rp, x.data_ptr(), _ld(x), cin_p
+            w.dt, w.lddt, w.x, w.ldx, w.C = dtt.data_ptr(), _ld(dtt), x.data_ptr(), _ld(x), cin_p
             w.dD, w.lddd = e.down_g.data_ptr(), kw
             if conv:
                 w.geom = g
@@ -517,13 +521,13 @@ def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p):
             nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
         else:                     # strided / resampled windows: two K-major GEMMs in one launch
             launch_gemm_pair(
-                dict(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy_ptr, ldb=lddy, b_trans=1,
+                dict(M=e.rp, N=npad, K=M, A=tt.data_ptr(), lda=_ld(tt), a_trans=1, B=dy_ptr, ldb=lddy, b_trans=1,
                      D=e.up_g.data_ptr(), ldd=_ld(e.up_g), out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
                      split_k=_split_k((npad + 63) // 64, M)),
-                dict(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
+                dict(M=e.rp, N=kw, K=M, A=dtt.data_ptr(), lda=_ld(dtt), a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
                      b_conv=1 if conv else 0, geom=g, D=e.down_g.data_ptr(), ldd=kw,
                      out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M)))
-        keep.append((t, dt))       # the launches above are asynchronous: hold the temporaries until the join
+        keep.append((tt, dtt))       # the launches above are asynchronous: hold the temporaries until the join
 
     if _side["enabled"]:
         _fork_side(work, keep)
@@ -550,6 +554,7 @@ class _LoraMerged(torch.autograd.Function):
         if conv and x.shape[0] != cfg.nimg * cfg.H * cfg.W:
             raise RuntimeError(f"t2v_amd: conv input rows {x.shape[0]} != nimg*H*W {cfg.nimg * cfg.H * cfg.W}")
         y = torch.empty(M, npad, dtype=BF16, device=x.device)
+        t = torch.empty(M, e.rp, dtype=BF16, device=x.device)       # t = x (*) D^T: rank columns of this launch, for dU only
         b32 = _pad_vec(_f32(bias), npad)
         rpr = 0
         if rowbias is not None:
@@ -557,18 +562,19 @@ class _LoraMerged(torch.autograd.Function):
             rpr = M // rowbias.shape[0]
         if residual is not None:
             residual = _mat(residual, "residual")
-        launch_gemm(M=M, N=npad, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(), ldd=npad,
+        launch_gemm(M=M, N=npad + e.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(), ldd=npad,
                     a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(e.cin_p) if conv else None, bias=nv.ptr(b32),
                     rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
-                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0)
+                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
+                    B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
         ctx.cfg, ctx.e, ctx.scale = cfg, e, scale
         ctx.has = (rowbias is not None, residual is not None)
-        ctx.save_for_backward(x, rowbias)
+        ctx.save_for_backward(x, rowbias, t)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, rowbias = ctx.saved_tensors
+        x, rowbias, t = ctx.saved_tensors
         cfg, e, scale = ctx.cfg, ctx.e, ctx.scale
         has_rb, has_res = ctx.has
         dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
@@ -578,13 +584,24 @@ class _LoraMerged(torch.autograd.Function):
         drb = None
         if has_rb:
             drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
-        dx = None
+        dx, dt = None, None
         if ctx.needs_input_grad[0]:
             wb = e.weff_bwd                            # [Cin_p, taps*Np], flipped taps
-            if cfg.kind == "linear":
+            if cfg.kind == "linear":                   # [dx | dt] = dy [W_eff | U]: dt rides as rank columns
                 dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
-                launch_gemm(M=M, N=cin_p, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=_ld(wb), D=dx.data_ptr(),
-                            ldd=cin_p)
+                dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)
+                launch_gemm(M=M, N=cin_p + e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=_ld(wb),
+                            D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p,
+                            D2=dt.data_ptr(), ldd2=e.rp)
+            elif e.rp <= 32 and _wgrad_window_ok(cfg.fwd_geom(cin_p), M) and cfg.taps() in (1, 3, 9):
+                # stride-1 same-size window: the rank columns' weights exist only at the tap that gathers the row itself
+                bg = cfg.bwd_geom(npad)
+                dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+                dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)
+                launch_gemm(M=M, N=cin_p + e.rp, K=cfg.taps() * npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(),
+                            ldb=_ld(wb), D=dx.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=bg, B2=e.up_w16.data_ptr(),
+                            ldb2=_ld(e.up_w16), n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp,
+                            b2_k0=(bg.py * bg.KW + bg.px) * npad, b2_klen=npad)
             else:
                 Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
                 Mi = cfg.nimg * Hv * Wv
@@ -597,7 +614,7 @@ class _LoraMerged(torch.autograd.Function):
                             nv.stream())
                 else:
                     dx = dxv
-        _lora_side_grads(x, dy.data_ptr(), _ld(dy), [dy, x], cfg, e, scale, M, npad, cin_p)
+        _lora_side_grads(x, dy.data_ptr(), _ld(dy), [dy, x, t, dt], cfg, e, scale, M, npad, cin_p, t=t, dt=dt)
         return dx, None, None, None, drb, dres, None, None, None
 
 
@@ -620,40 +637,37 @@ class _LoraGroupMerged(torch.autograd.Function):
             raise RuntimeError("t2v_amd: projection group does not match its layers")
         M = x.shape[0]
         y = torch.empty(M, ncat, dtype=BF16, device=x.device)
-        launch_gemm(M=M, N=ncat, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(), ldd=ncat)
+        t = torch.empty(M, g.rp, dtype=BF16, device=x.device)
+        launch_gemm(M=M, N=ncat + g.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(), ldd=ncat,
+                    B2=g.down_w16.data_ptr(), ldb2=K, n_split=ncat, D2=t.data_ptr(), ldd2=g.rp)
         ctx.g, ctx.scale = g, scale
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, t)
         return tuple(y[:, i * g.npad_each:(i + 1) * g.npad_each] for i in range(g.n))
 
     @staticmethod
     def backward(ctx, *dys):
-        (x,) = ctx.saved_tensors
+        x, t = ctx.saved_tensors
         g, scale = ctx.g, ctx.scale
         n, M = g.n, x.shape[0]
         if any(d is None for d in dys):
             dys = [d if d is not None else torch.zeros(M, g.npad_each, dtype=BF16, device=x.device) for d in dys]
         if _adjacent_columns(dys):
             dy_ptr, lddy = dys[0].data_ptr(), dys[0].stride(0)
-            keep = [dys, x]
+            keep = [dys, x, t]
         else:
             dcat = torch.cat([_mat(d if d.stride(1) == 1 else d.contiguous(), "dy") for d in dys], dim=1)
             dy_ptr, lddy = dcat.data_ptr(), dcat.stride(0)
-            keep = [dcat, x]
+            keep = [dcat, x, t]
         cin_p, ncat = g.cin_p, g.npad
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wb = g.weff_bwd
-            dx = torch.empty(M, cin_p, dtype=BF16, device=x.device)
-            launch_gemm(M=M, N=cin_p, K=ncat, A=dy_ptr, lda=lddy, B=wb.data_ptr(), ldb=_ld(wb), D=dx.data_ptr(), ldd=cin_p)
+        wb = g.weff_bwd
+        dx = torch.empty(M, cin_p, dtype=BF16, device=x.device)
+        dt = torch.empty(M, g.rp, dtype=BF16, device=x.device)      # [dx | dt_cat] = dy_cat [W_eff,cat | U_blk]
+        launch_gemm(M=M, N=cin_p + g.rp, K=ncat, A=dy_ptr, lda=lddy, B=wb.data_ptr(), ldb=_ld(wb), D=dx.data_ptr(), ldd=cin_p,
+                    B2=g.up_w16.data_ptr(), ldb2=ncat, n_split=cin_p, D2=dt.data_ptr(), ldd2=g.rp)
+        keep.append(dt)
         rpe, npe = g.rp_each, g.npad_each
 
         def work():
-            t = torch.empty(M, g.rp, dtype=BF16, device=x.device)
-            dt = torch.empty(M, g.rp, dtype=BF16, device=x.device)
-            launch_gemm(M=M, N=g.rp, K=cin_p, A=x.data_ptr(), lda=_ld(x), B=g.down_w16.data_ptr(), ldb=cin_p, D=t.data_ptr(),
-                        ldd=g.rp, use_ws=False)
-            launch_gemm(M=M, N=g.rp, K=ncat, A=dy_ptr, lda=lddy, B=g.up_w16.data_ptr(), ldb=ncat, D=dt.data_ptr(), ldd=g.rp,
-                        use_ws=False)
             for i in range(n):
                 w = nv.LoraWgrad()
                 w.rows, w.rp, w.conv = M, rpe, 0
@@ -665,13 +679,12 @@ class _LoraGroupMerged(torch.autograd.Function):
                 w.dD, w.lddd = g.down_g.data_ptr() + i * rpe * cin_p * 4, cin_p
                 w.alpha = scale
                 nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
-            keep.append((t, dt))
 
         if _side["enabled"]:
             _fork_side(work, keep)
         else:
             work()
-        return (dx, None, None) + (None,) * (2 * n)
+        return (dx if ctx.needs_input_grad[0] else None, None, None) + (None,) * (2 * n)
 
 
 def lora_group_merged(x, group, scale):
