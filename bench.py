@@ -24,9 +24,17 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 CONFIGS = {
-    # name: (frames, height, width, lora_rank)
+    # name: (frames, height, width, lora_rank)   rank 0 = full UNet finetune (no LoRA)
     "c2": (16, 256, 256, 16),     # BASELINE.json configs[1] — the configuration the metric is quoted on
     "c1": (8, 128, 128, 4),       # configs[0] — the reference's CPU-runnable case
+    "c3": (16, 256, 256, 0),      # configs[2] — full UNet finetune (1.41 B trainable), gradient checkpointing off
+    "c4": (24, 320, 576, 16),     # configs[3] — one clip of the Zeroscope-576w shape (24 frames @576x320, latent 40x72) per GPU
+}
+METRICS = {
+    "c2": "train-step videos/sec (16-frame 256x256, ModelScope-1.7B LoRA)",
+    "c1": "train-step videos/sec (8-frame 128x128, ModelScope-1.7B LoRA r=4)",
+    "c3": "train-step videos/sec (16-frame 256x256, ModelScope-1.7B full UNet finetune)",
+    "c4": "train-step videos/sec (24-frame 576x320, Zeroscope-576w shape, LoRA r=16)",
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # HBM3E peak, same guide
@@ -41,14 +49,18 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (median is reported; one untimed warm-up first)")
+    ap.add_argument("--dropout", action="store_true",
+                    help="the reference's default train mode: LoRA dropout 0.1 (utils/lora.py:35,89) and TemporalConvLayer "
+                         "dropout 0.1 (models/unet_3d_blocks.py:312) instead of its eval_train mode; eager launches")
+    ap.add_argument("--grad-checkpointing", action="store_true", help="train.py:127-129,670-675")
     ap.add_argument("--no-text-encoder", action="store_true", help="feed synthetic text states instead of running CLIP")
     ap.add_argument("--export-tune-table", default=None,
                     help="write the GEMM tile table after the run (use with T2V_GEMM_AUTOTUNE=live; scripts/tune_gemm_table.sh)")
     return ap.parse_args()
 
 
-def build_models(frames, lora_rank, device, seed):
+def build_models(frames, lora_rank, device, seed, dropout=False, grad_ckpt=False):
     import t2v_amd  # noqa: F401
     from t2v_amd.models.unet_3d_condition import UNet3DConditionModel
     from t2v_amd.models.vae import AutoencoderKL
@@ -61,14 +73,20 @@ def build_models(frames, lora_rank, device, seed):
             if m.__class__.__name__ == "TemporalConvLayer":
                 c = m.conv4[-1].weight.shape[1]
                 torch.nn.init.normal_(m.conv4[-1].weight, std=(3 * c) ** -0.5)
-    unet.requires_grad_(False)
     vae.requires_grad_(False)
-    handler = LoraHandler(use_unet_lora=True)
-    params, _ = handler.add_lora_to_model(True, unet, ["UNet3DConditionModel"], 0.0, None, r=lora_rank)
+    if lora_rank > 0:
+        unet.requires_grad_(False)
+        handler = LoraHandler(use_unet_lora=True)
+        handler.add_lora_to_model(True, unet, ["UNet3DConditionModel"], 0.1 if dropout else 0.0, None, r=lora_rank)
+    else:
+        unet.requires_grad_(True)                       # config C3: every UNet parameter trains (train.py:172-236 param groups)
     unet.train()
-    for m in unet.modules():                            # the reference's `eval_train` mode (train.py:779-781): dropout off
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
+    if not dropout:
+        for m in unet.modules():                        # the reference's `eval_train` mode (train.py:779-781): dropout off
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    if grad_ckpt:
+        unet.enable_gradient_checkpointing()
     vae.eval()
     trainable = [p for p in unet.parameters() if p.requires_grad]
     return unet, vae, trainable
@@ -138,17 +156,35 @@ def gemm_roofline(trainer, batch):
         e.record()
         records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False))
 
-    conv3d, attn, wgrad, shapes = [], [], [], []
+    conv3d, attn, wgrad, shapes, norms = [], [], [], [], []
     nv = F.nv
     orig_call = nv.call
 
+    NORM = {"t2v_gn_stats": (2, "gn_fwd"), "t2v_gn_apply": (4, "gn_fwd"), "t2v_gn_bwd_stats": (4, "gn_bwd"),
+            "t2v_gn_bwd_apply": (6, "gn_bwd"), "t2v_layernorm_fwd": (None, "ln_fwd"), "t2v_layernorm_bwd": (None, "ln_bwd")}
+
     def timed_call(name, *a):
-        if name not in ("t2v_attn_fwd", "t2v_attn_bwd", "t2v_lora_wgrad"):
+        if name not in ("t2v_attn_fwd", "t2v_attn_bwd", "t2v_lora_wgrad") and name not in NORM:
             return orig_call(name, *a)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = orig_call(name, *a)
         e.record()
+        if name in NORM:
+            pos, kind = NORM[name]
+            if pos is None:                      # layernorm_fwd(x,ldx,y,ldy,rows,C,..) / bwd(x,ldx,dy,lddy,dx,lddx,rows,C,..)
+                E = float(a[4] * a[5]) if name.endswith("fwd") else float(a[6] * a[7])
+                moved = 2 * E * 2 if name.endswith("fwd") else (3 + (1 if a[-3] else 0)) * E * 2
+                alg = moved
+            else:
+                E = float(a[pos]) * a[pos + 1] * a[pos + 2]
+                addend = name == "t2v_gn_bwd_apply" and a[-3]
+                moved = {"t2v_gn_stats": 1, "t2v_gn_apply": 2, "t2v_gn_bwd_stats": 2, "t2v_gn_bwd_apply": 3 + (1 if addend else 0)}[name] * E * 2
+                # algorithmic minimum: forward reads x once and writes y once (statistics from the same read);
+                # backward reads x and dy once and writes dx (+ reads the residual gradient it absorbs)
+                alg = {"t2v_gn_stats": 0, "t2v_gn_apply": 2, "t2v_gn_bwd_stats": 0, "t2v_gn_bwd_apply": 3 + (1 if addend else 0)}[name] * E * 2
+            norms.append((kind, alg, moved, s, e))
+            return r
         d = a[0]._obj
         if name == "t2v_lora_wgrad":      # each activation operand read once; fp32 factor gradients accumulated
             taps = d.geom.KH * d.geom.KW if d.conv else 1
@@ -196,6 +232,16 @@ def gemm_roofline(trainer, batch):
         if rs:
             ns[f"{kind}_attention_core"] = both_roofs(sum(r[1] for r in rs), sum(r[2] for r in rs),
                                                       sum(r[3].elapsed_time(r[4]) for r in rs), len(rs))
+    for kind in ("gn_fwd", "gn_bwd", "ln_fwd", "ln_bwd"):
+        rs = [r for r in norms if r[0] == kind]
+        if rs:
+            ms = sum(r[3].elapsed_time(r[4]) for r in rs)
+            alg, moved = sum(r[1] for r in rs), sum(r[2] for r in rs)
+            ns[{"gn_fwd": "groupnorm_fwd(stats+apply)", "gn_bwd": "groupnorm_bwd(stats+apply)", "ln_fwd": "layernorm_fwd",
+                "ln_bwd": "layernorm_bwd"}[kind]] = {
+                "launches": len(rs), "ms_per_step": round(ms, 3), "algorithmic_GB_per_step": round(alg / 1e9, 3),
+                "GB/s": round(alg / ms / 1e6, 1), "frac_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "moved_GB_per_step": round(moved / 1e9, 3), "moved_GB/s": round(moved / ms / 1e6, 1)}
     out["north_star"] = ns
     if os.environ.get("T2V_BENCH_SHAPE_TABLE"):      # per-problem-signature GEMM time of one step (diagnostic)
         agg = {}
@@ -220,18 +266,21 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(steps):
-    """The CPU oracle (restatement of the reference path; the reference itself needs diffusers, absent offline)
-    timed on the host cores: full train step of config C1 (8 frames @128x128, LoRA r=4, batch 1)."""
+def cpu_baseline(steps, device):
+    """The CPU oracle (restatement of the reference path; the reference itself needs diffusers, absent offline) timed on
+    the host cores: full train steps of config C1 (8 frames @128x128, LoRA r=4, batch 1), one untimed warm-up, then the
+    MEDIAN of `steps` timed steps.  The first (warm-up) step doubles as the in-run parity check: the native trainer
+    evaluates the eps-MSE of the same weights and inputs on the GPU -> `eps_mse_rel_err` (bar: 1e-3)."""
+    import statistics
+    from oracle.fastconv import fast_temporal_conv3d
     from oracle.lora import inject_trainable_lora_extended
-    from oracle.train_step import train_step
+    from oracle.train_step import finetune_unet_loss, train_step
     from oracle.unet3d import UNet3DConditionModel
     from oracle.vae import AutoencoderKLEncoder
     from oracle.weights import randomize_temporal_conv4, synthetic_batch as obatch
     frames, H, W, r = CONFIGS["c1"]
     torch.manual_seed(0)
-    dev = "cuda" if torch.cuda.is_available() else "cpu"      # build on the GPU only to make random init fast
-    with torch.device(dev):
+    with torch.device(device):                                 # random init on the GPU only to make it fast
         unet = UNet3DConditionModel()
         vae = AutoencoderKLEncoder()
     unet, vae = unet.cpu(), vae.cpu().eval()
@@ -243,38 +292,92 @@ def cpu_baseline(steps):
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     unet.train()
+    cores = max(1, min(32, os.cpu_count() or 1))              # oneDNN stops scaling (and oversubscribes) beyond ~32 threads here
+    torch.set_num_threads(cores)
+    # ---- in-run parity: same weights, same host-drawn batch, native path on the GPU vs oracle on the CPU
+    batch = obatch(frames, H, W, seed=1234)
+    rel, l_cpu, l_gpu = None, None, None
+    try:
+        import t2v_amd  # noqa: F401
+        from t2v_amd.models.unet_3d_condition import UNet3DConditionModel as DUNet
+        from t2v_amd.models.vae import AutoencoderKL
+        from t2v_amd.training import DenoiseTrainer
+        from t2v_amd.utils.lora import inject_trainable_lora_extended as dinject
+        with torch.device("meta"):
+            dunet, dvae = DUNet(), AutoencoderKL()
+        dunet, dvae = dunet.to_empty(device=device), dvae.to_empty(device=device)
+        dunet.requires_grad_(False); dvae.requires_grad_(False)
+        dinject(dunet, {"UNet3DConditionModel"}, r=r)
+        dunet.load_state_dict(unet.state_dict(), strict=True); dvae.load_state_dict(vae.state_dict(), strict=True)
+        for m in dunet.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        dunet.train()
+        tr = DenoiseTrainer(dunet, dvae.eval(), [p for p in dunet.parameters() if p.requires_grad], lr=5e-6)
+        with torch.no_grad():
+            l_gpu = float(tr.loss_fn({k: v.to(device) for k, v in batch.items()}))
+        del tr, dunet, dvae
+        torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001
+        print(f"[bench] in-run parity check failed: {type(e).__name__}: {e}", file=sys.stderr)
     params = [p for p in unet.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
-    from oracle.fastconv import fast_temporal_conv3d
-    cores = torch.get_num_threads()
     times = []
     with fast_temporal_conv3d():      # (3,1,1) Conv3d evaluated as a (3,1) conv2d: same arithmetic, oneDNN fast path
+        # warm-up step (untimed) = the parity reference: loss BEFORE any update
+        lw, _ = finetune_unet_loss(unet, vae, batch)
+        l_cpu = float(lw.detach())
+        lw.backward()
+        opt.step(); opt.zero_grad(set_to_none=True)
         for i in range(steps):
-            batch = obatch(frames, H, W, seed=1234 + i)
+            b = obatch(frames, H, W, seed=2000 + i)
             t0 = time.time()
-            train_step(unet, vae, batch, opt)
+            train_step(unet, vae, b, opt)
             times.append(time.time() - t0)
-    best = min(times)
-    return dict(value=1.0 / best, unit="videos/s", cores=cores, kind="port",
-                sample=f"{steps} full train step(s) of config C1 (8 frames @128x128, LoRA r=4, fp32, PyTorch CPU oracle, "
-                       f"temporal Conv3d run as conv2d), best step {best:.2f} s; a C1 clip is ~1/8 of the C2 clip's work")
+    if l_gpu is not None:
+        rel = abs(l_gpu - l_cpu) / abs(l_cpu)
+    med = statistics.median(times)
+    return dict(value=1.0 / med, unit="videos/s", cores=cores, kind="port",
+                sample=f"median of {steps} full train steps of config C1 (8 frames @128x128, LoRA r=4, fp32, PyTorch CPU oracle on "
+                       f"{cores} threads, temporal Conv3d run as conv2d) after one warm-up step: {med:.2f} s/step "
+                       f"(all: {', '.join(f'{t:.1f}' for t in times)}); a C1 clip is ~1/8 of the C2 clip's work",
+                eps_mse_rel_err=rel, eps_mse_cpu=l_cpu, eps_mse_gpu=l_gpu,
+                eps_mse_note="same seeded ModelScope-1.7B weights and C1 batch: native trainer loss on the GPU vs the CPU fp32 oracle, "
+                             "this run; the C2-size check (3.9e-5) is tests/test_lora_grads_gpu.py against the committed oracle fixture")
+
+
+def _self_spawn(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-launch under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_spawn(args)
     import t2v_amd  # noqa: F401
     from t2v_amd.parallel import init_from_env
     from t2v_amd.training import DenoiseTrainer
     rank, world, local = init_from_env("nccl" if args.gpus > 1 else None)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU path in the product)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     frames, H, W, r = CONFIGS[args.config]
 
-    unet, vae, trainable = build_models(frames, r, dev, seed=0)            # same frozen weights on every rank
+    unet, vae, trainable = build_models(frames, r, dev, seed=0, dropout=args.dropout,
+                                        grad_ckpt=args.grad_checkpointing)   # same frozen weights on every rank
     text_encoder = None if args.no_text_encoder else build_text_encoder(dev)
     trainer = DenoiseTrainer(unet, vae, trainable, lr=5e-6, world_size=world, text_encoder=text_encoder)
     if world > 1:
@@ -282,7 +385,7 @@ def main():
         broadcast_params(trainer.opt.flat_p)
     batch = synthetic_batch(frames, H, W, dev, seed=1234 + rank, with_ids=text_encoder is not None)   # one clip per GPU
 
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and not args.dropout       # active dropout draws fresh masks per step: eager launches
     text_mode = "clip-in-step" if text_encoder is not None else "synthetic"
     if use_graph:
         try:
@@ -346,21 +449,26 @@ def main():
                     north_star_kernels=both["north_star"])
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_steps)
+        cpu = cpu_baseline(args.cpu_steps, dev)
 
     if rank == 0:
         out = {
-            "metric": "train-step videos/sec (16-frame 256x256, ModelScope-1.7B LoRA)" if args.config == "c2"
-                      else "train-step videos/sec (8-frame 128x128, ModelScope-1.7B LoRA r=4)",
+            "metric": METRICS[args.config],
             "value": round(args.steps * world / dt, 4), "unit": "videos/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: ModelScope-1.7B UNet3D + SD-VAE encode, {frames} frames @{H}x{W}, "
-                                   f"LoRA r={r} on all 574 Linear/Conv layers, batch 1 clip/GPU, 2 UNet passes/step, "
-                                   f"dropout off (reference eval_train mode), text encoder: {text_mode}",
+            "config": {"workload": f"{args.config}: ModelScope-1.7B UNet3D + SD-VAE encode, {frames} frames @{W}x{H}, "
+                                   + (f"LoRA r={r} on all 574 Linear/Conv layers" if r > 0 else "full UNet finetune (no LoRA)")
+                                   + f", batch 1 clip/GPU, 2 UNet passes/step, "
+                                   + ("LoRA dropout 0.1 + TemporalConvLayer dropout 0.1 (reference default train mode)" if args.dropout
+                                      else "dropout off (reference eval_train mode)")
+                                   + (", gradient checkpointing on" if args.grad_checkpointing else "")
+                                   + f", text encoder: {text_mode}",
                        "global_batch": world, "parallelism": f"dp{world}", "graph_replay": use_graph,
                        "trainable_params": sum(p.numel() for p in trainer.opt.params),
-                       "flat_gradient_elems": trainer.opt.numel, "final_loss": final_loss},
+                       "flat_gradient_elems": trainer.opt.numel, "final_loss": final_loss,
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                       "eps_mse_rel_err": (cpu or {}).get("eps_mse_rel_err")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

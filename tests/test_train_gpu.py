@@ -202,3 +202,39 @@ def test_plain_backward_joins_factor_gradient_stream():
     tr.opt.step()
     torch.cuda.synchronize()
     assert torch.isfinite(gn) and gn > 0
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_gradient_checkpointing_recomputes_the_same_step(dropout):
+    """a18 (models/unet_3d_blocks.py:30-153, toggled by train.py:127-129,670-675): with `gradient_checkpointing` on, every
+    resnet / temp_conv / attention / temporal-attention call is re-run in backward instead of keeping its activations.
+    Loss and LoRA gradients must equal the plain step (up to the fp32 atomics of the factor-gradient reductions) — also with
+    dropout active, where the recompute has to regenerate the masks of the first run — and the activation peak must drop."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.models import leaves
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4)
+    if dropout:
+        for n, m in dunet.named_modules():
+            if isinstance(m, torch.nn.Dropout) and ("temp_convs" in n or n.endswith(".dropout")):
+                m.p = 0.1
+    params = [p for p in dunet.parameters() if p.requires_grad]
+    tr = DenoiseTrainer(dunet, dvae, params, lr=1e-4)
+    batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=9, text_dim=64).items()}
+
+    def run(ckpt):
+        dunet._set_gradient_checkpointing(value=ckpt)
+        leaves.set_dropout_seed(1234)
+        tr.opt.zero_grad()
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss = tr._fwd_bwd(batch)
+        torch.cuda.synchronize()
+        return float(loss), tr.opt.flat_g.clone(), torch.cuda.max_memory_allocated() - base
+
+    l0, g0, m0 = run(False)
+    l1, g1, m1 = run(True)
+    print(f"checkpointing (dropout={dropout}): loss {l0:.6f} / {l1:.6f}, grad relerr {relerr(g1, g0):.2e}, activation peak {m0 / 2**20:.0f} -> {m1 / 2**20:.0f} MiB")
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert float(g0.norm()) > 0 and relerr(g1, g0) < 1e-3
+    assert m1 < 0.7 * m0

@@ -22,6 +22,34 @@ def _cat(h, skip):
     return Tok(F.concat(h.m, skip.m), h.n, h.h, h.w)
 
 
+def checkpointed(fn, *args, **kwargs):
+    """`torch.utils.checkpoint(..., use_reentrant=False)` around one sub-module call — the reference's per-sub-module
+    recompute (`custom_checkpoint` / `cross_attn_g_c` / `up_down_g_c` / `transformer_g_c`, models/unet_3d_blocks.py:30-153):
+    nothing the call saves for backward is kept; the call is re-run when its gradient is needed.  The dropout seed counter
+    (models/leaves.py) is rewound for the re-run so that it regenerates the masks of the first run."""
+    from torch.utils.checkpoint import checkpoint
+    from . import leaves
+    start = leaves._seed_state["ctr"]
+
+    def run(*a, **k):
+        later = leaves._seed_state["ctr"]
+        leaves._seed_state["ctr"] = start
+        out = fn(*a, **k)
+        leaves._seed_state["ctr"] = max(later, leaves._seed_state["ctr"])
+        return out
+
+    return checkpoint(run, *args, use_reentrant=False, **kwargs)
+
+
+def _call(block, mod, *args, **kwargs):
+    """Run sub-module `mod` of `block`, recomputed in backward when the block's `gradient_checkpointing` flag is set
+    (train.py:127-129,670-675 -> `_set_gradient_checkpointing`)."""
+    import torch
+    if getattr(block, "gradient_checkpointing", False) and torch.is_grad_enabled():
+        return checkpointed(mod, *args, **kwargs)
+    return mod(*args, **kwargs)
+
+
 class UNetMidBlock3DCrossAttn(nn.Module):
     def __init__(self, in_channels, temb_channels, dropout=0.0, num_layers=1, resnet_eps=1e-6,
                  resnet_time_scale_shift="default", resnet_act_fn="swish", resnet_groups=32, resnet_pre_norm=True,
@@ -51,17 +79,17 @@ class UNetMidBlock3DCrossAttn(nn.Module):
 
     def forward(self, hidden_states, temb=None, encoder_hidden_states=None, attention_mask=None, num_frames=1,
                 cross_attention_kwargs=None):
-        hidden_states = self.resnets[0](hidden_states, temb)
-        hidden_states = self.temp_convs[0](hidden_states, num_frames=num_frames)
+        hidden_states = _call(self, self.resnets[0], hidden_states, temb)
+        hidden_states = _call(self, self.temp_convs[0], hidden_states, num_frames=num_frames)
         for attn, temp_attn, resnet, temp_conv in zip(self.attentions, self.temp_attentions, self.resnets[1:],
                                                       self.temp_convs[1:]):
-            hidden_states = attn(hidden_states, encoder_hidden_states=encoder_hidden_states,
-                                 num_frames=num_frames).sample
+            hidden_states = _call(self, attn, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                  num_frames=num_frames).sample
             if num_frames > 1:
-                hidden_states = temp_attn(hidden_states, num_frames=num_frames).sample
-            hidden_states = resnet(hidden_states, temb)
+                hidden_states = _call(self, temp_attn, hidden_states, num_frames=num_frames).sample
+            hidden_states = _call(self, resnet, hidden_states, temb)
             if num_frames > 1:
-                hidden_states = temp_conv(hidden_states, num_frames=num_frames)
+                hidden_states = _call(self, temp_conv, hidden_states, num_frames=num_frames)
         return hidden_states
 
 
@@ -101,13 +129,13 @@ class CrossAttnDownBlock3D(nn.Module):
         output_states = ()
         for resnet, temp_conv, attn, temp_attn in zip(self.resnets, self.temp_convs, self.attentions,
                                                       self.temp_attentions):
-            hidden_states = resnet(hidden_states, temb)
+            hidden_states = _call(self, resnet, hidden_states, temb)
             if num_frames > 1:
-                hidden_states = temp_conv(hidden_states, num_frames=num_frames)
-            hidden_states = attn(hidden_states, encoder_hidden_states=encoder_hidden_states,
-                                 num_frames=num_frames).sample
+                hidden_states = _call(self, temp_conv, hidden_states, num_frames=num_frames)
+            hidden_states = _call(self, attn, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                  num_frames=num_frames).sample
             if num_frames > 1:
-                hidden_states = temp_attn(hidden_states, num_frames=num_frames).sample
+                hidden_states = _call(self, temp_attn, hidden_states, num_frames=num_frames).sample
             output_states += (hidden_states,)
         if self.downsamplers is not None:
             for d in self.downsamplers:
@@ -137,9 +165,9 @@ class DownBlock3D(nn.Module):
     def forward(self, hidden_states, temb=None, num_frames=1):
         output_states = ()
         for resnet, temp_conv in zip(self.resnets, self.temp_convs):
-            hidden_states = resnet(hidden_states, temb)
+            hidden_states = _call(self, resnet, hidden_states, temb)
             if num_frames > 1:
-                hidden_states = temp_conv(hidden_states, num_frames=num_frames)
+                hidden_states = _call(self, temp_conv, hidden_states, num_frames=num_frames)
             output_states += (hidden_states,)
         if self.downsamplers is not None:
             for d in self.downsamplers:
@@ -185,13 +213,13 @@ class CrossAttnUpBlock3D(nn.Module):
                                                       self.temp_attentions):
             res = res_hidden_states_tuple[-1]
             res_hidden_states_tuple = res_hidden_states_tuple[:-1]
-            hidden_states = resnet(_cat(hidden_states, res), temb)
+            hidden_states = _call(self, resnet, _cat(hidden_states, res), temb)
             if num_frames > 1:
-                hidden_states = temp_conv(hidden_states, num_frames=num_frames)
-            hidden_states = attn(hidden_states, encoder_hidden_states=encoder_hidden_states,
-                                 num_frames=num_frames).sample
+                hidden_states = _call(self, temp_conv, hidden_states, num_frames=num_frames)
+            hidden_states = _call(self, attn, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                  num_frames=num_frames).sample
             if num_frames > 1:
-                hidden_states = temp_attn(hidden_states, num_frames=num_frames).sample
+                hidden_states = _call(self, temp_attn, hidden_states, num_frames=num_frames).sample
         if self.upsamplers is not None:
             for u in self.upsamplers:
                 hidden_states = u(hidden_states, upsample_size)
@@ -220,9 +248,9 @@ class UpBlock3D(nn.Module):
         for resnet, temp_conv in zip(self.resnets, self.temp_convs):
             res = res_hidden_states_tuple[-1]
             res_hidden_states_tuple = res_hidden_states_tuple[:-1]
-            hidden_states = resnet(_cat(hidden_states, res), temb)
+            hidden_states = _call(self, resnet, _cat(hidden_states, res), temb)
             if num_frames > 1:
-                hidden_states = temp_conv(hidden_states, num_frames=num_frames)
+                hidden_states = _call(self, temp_conv, hidden_states, num_frames=num_frames)
         if self.upsamplers is not None:
             for u in self.upsamplers:
                 hidden_states = u(hidden_states, upsample_size)

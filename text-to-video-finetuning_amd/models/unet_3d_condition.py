@@ -135,8 +135,9 @@ class UNet3DConditionModel(nn.Module, ModelMixinLite):
         text = TextCtx(encoder_hidden_states)
         x = Tok.from_nchw(sample.permute(0, 2, 1, 3, 4).reshape(B * num_frames, Cin, h, w))
         x = Tok(run_layer(self.conv_in, x.m, ConvCfg.conv2d(x.n, h, w, 3, 1, 1)), x.n, h, w)
-        if num_frames > 1:
-            x = self.transformer_in(x, num_frames=num_frames).sample
+        if num_frames > 1:       # models/unet_3d_condition.py:407-411 (transformer_g_c when checkpointing)
+            from .unet_3d_blocks import _call
+            x = _call(self, self.transformer_in, x, num_frames=num_frames).sample
         res_samples = (x,)
         for blk in self.down_blocks:
             if getattr(blk, "has_cross_attention", False):

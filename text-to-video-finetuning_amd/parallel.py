@@ -31,14 +31,20 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def allreduce_flat_grads(flat_g, world, group=None, loss=None):
-    """SUM-all-reduce the flat gradient buffer (and optionally the loss, appended to the same message).
-    Returns (grad_scale, mean_loss_or_None); grad_scale = 1/world is applied by the optimizer kernel."""
+def allreduce_flat_grads(flat_g, world, group=None, loss=None, tail=None):
+    """SUM-all-reduce the flat gradient buffer; returns (grad_scale, mean_loss_or_None), grad_scale = 1/world being applied
+    by the optimizer kernel.  `tail`: index of a spare slot INSIDE `flat_g` (behind the gradients) that carries the loss
+    through the same collective — no concatenation copy, no second collective (the reference all_gathers the loss per
+    micro-step, train.py:856).  Without `tail` the loss is appended to a copy of the buffer (helper form)."""
     if world <= 1:
         return 1.0, loss
     if loss is None:
         dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / world, None
+    if tail is not None:
+        flat_g[tail] = loss.detach().to(flat_g.dtype)
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / world, flat_g[tail] / world
     buf = torch.cat([flat_g, loss.detach().reshape(1).to(flat_g.dtype)])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     flat_g.copy_(buf[:-1])

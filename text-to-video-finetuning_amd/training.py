@@ -76,7 +76,10 @@ class FlatAdamW:
         n = sum(sizes)
         self.numel = n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        # 8 spare floats behind the gradients: slot n carries the loss through the SAME all-reduce (train.py:856 gathers it
+        # with a separate collective per micro-step)
+        self.flat_g_full = torch.zeros(n + 8, dtype=torch.float32, device=dev)
+        self.flat_g = self.flat_g_full[:n]
         self.flat_p16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -121,7 +124,7 @@ class FlatAdamW:
 
     def zero_grad(self, set_to_none=False):
         self._ensure_homed()
-        self.flat_g.zero_()
+        self.flat_g_full.zero_()
 
     def grad_norm(self):
         return self.sumsq.sqrt()
@@ -253,16 +256,18 @@ class DenoiseTrainer:
         join_side_stream()                 # factor-gradient launches (side stream) complete before clip/AdamW/all-reduce
         return loss.detach()
 
-    def _exchange_and_update(self):
+    def _exchange_and_update(self, loss):
+        """DP exchange (train.py:661-667,856): ONE all-reduce(SUM) of the flat gradient buffer over RCCL/xGMI whose tail slot
+        carries this rank's loss; returns the rank-mean loss (what the reference logs after `accelerator.gather`)."""
         from .parallel import allreduce_flat_grads
-        scale, _ = allreduce_flat_grads(self.opt.flat_g, self.world, self.pg)   # RCCL over xGMI: one flat buffer
+        scale, mean_loss = allreduce_flat_grads(self.opt.flat_g_full, self.world, self.pg, loss=loss, tail=self.opt.numel)
         self.opt.step(grad_scale=scale, refresh=False)     # _fwd_bwd refreshes the bf16 copies (inside the captured step)
+        return mean_loss
 
     def train_step(self, batch):
         self.opt.zero_grad()
         loss = self._fwd_bwd(batch)
-        self._exchange_and_update()
-        return loss
+        return self._exchange_and_update(loss)
 
     # ---- HIP-graph replay of forward+backward (static shapes)
     def capture(self, batch, warmup=2):
@@ -299,5 +304,4 @@ class DenoiseTrainer:
                     self._static[k].copy_(v)
         self.opt.zero_grad()
         self._graph.replay()
-        self._exchange_and_update()
-        return self._static_loss
+        return self._exchange_and_update(self._static_loss)
