@@ -132,6 +132,9 @@ class UNet3DConditionModel(nn.Module, ModelMixinLite):
         timesteps = timesteps.expand(B)
         t_emb = self.time_proj(timesteps)
         temb = Temb(self.time_embedding(t_emb, timestep_cond))          # [B, 1280]; broadcast per video in the conv epilogue
+        if getattr(self, "gradient_checkpointing", False):
+            temb.act          # materialise the shared SiLU(temb) OUTSIDE the checkpointed calls (a recompute must save what the
+            #                   first run saved; a lazily cached activation would be computed in one and not in the other)
         text = TextCtx(encoder_hidden_states)
         x = Tok.from_nchw(sample.permute(0, 2, 1, 3, 4).reshape(B * num_frames, Cin, h, w))
         x = Tok(run_layer(self.conv_in, x.m, ConvCfg.conv2d(x.n, h, w, 3, 1, 1)), x.n, h, w)
