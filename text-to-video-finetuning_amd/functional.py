@@ -354,25 +354,33 @@ def _fork_side(work, keep):
             join_side_stream()
 
 
-def _lowrank_update(y, t, u, M, N, r, scale):
-    """y[M,N] += scale * t[M,r] @ u[r,N] (streaming rank-r update kernel; other ranks go through the GEMM)."""
+def _lowrank_update(y, t, u, M, N, r, scale, drop_p=0.0, drop_seed=0):
+    """y[M,N] += scale * drop(t[M,r] @ u[r,N]) (streaming rank-r update kernel; other ranks go through the GEMM)."""
     if r in (8, 16, 24, 32, 48, 64, 96):
-        nv.call("t2v_lowrank_update", y.data_ptr(), _ld(y), t.data_ptr(), _ld(t), u.data_ptr(), _ld(u), M, N, r, scale,
-                nv.stream())
+        if drop_p > 0.0:
+            nv.call("t2v_lowrank_update_drop", y.data_ptr(), _ld(y), t.data_ptr(), _ld(t), u.data_ptr(), _ld(u), M, N, r, scale,
+                    drop_p, drop_seed, nv.stream())
+        else:
+            nv.call("t2v_lowrank_update", y.data_ptr(), _ld(y), t.data_ptr(), _ld(t), u.data_ptr(), _ld(u), M, N, r, scale,
+                    nv.stream())
+    elif drop_p > 0.0:
+        raise RuntimeError(f"t2v_amd: LoRA dropout in the fused layer needs a padded rank in (8..96), got {r}")
     else:
         launch_gemm(M=M, N=N, K=r, A=t.data_ptr(), lda=_ld(t), B=u.data_ptr(), ldb=_ld(u), b_trans=1, D=y.data_ptr(), ldd=_ld(y),
                     R=y.data_ptr(), ldr=_ld(y), alpha=scale)
 
 
 class _LoraLayer(torch.autograd.Function):
-    """One LoRA-wrapped layer: y = base(x) + scale * up(down(x)) (utils/lora.py:57-62,134-139,211-216, dropout off /
-    identity selector) with the factors living in the trainer's flat buffers (lora_bank.py):
-      fwd : [y | t] = x (*) [W ; D]^T in ONE launch (the down projection rides as extra output columns), y += s t U^T
-      bwd : dt = s dy U ; dx = dy (*) W^T + dt (*) D^T ; dU += s dy^T t ; dD += dt^T x   (TN GEMMs accumulate straight
-            into the flat fp32 gradient buffer)."""
+    """One LoRA-wrapped layer with the LoRA branch kept apart from the base weight:
+      y = base(x) + scale * dropout(up(down(x)))        (utils/lora.py:57-62,134-139,211-216, identity selector)
+    — the form needed when the wrapper's dropout is active (the reference's default train mode, dropout_p = 0.1:
+    utils/lora.py:35,89), where the branch cannot be merged into the weight; also the T2V_LORA_MERGE=0 path.
+      fwd : [y | t] = x (*) [W ; D]^T in ONE launch (the down projection rides as rank columns), y += s mask (t U^T)
+      bwd : g = mask dy ; dt = g U ; dx = dy (*) W^T + s dt (*) D^T ; dU += s t^T g ; dD += s dt^T x
+    With dropout off, g = dy and dt rides in the backward-data launch as rank columns."""
 
     @staticmethod
-    def forward(ctx, x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, e, scale):
+    def forward(ctx, x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, e, scale, drop_p=0.0, drop_seed=0):
         x = _mat(x, "x")
         wq = prepared_weight(w_base, "fwd")
         npad, K = wq.shape
@@ -395,8 +403,8 @@ class _LoraLayer(torch.autograd.Function):
                     rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
                     R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
                     B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
-        _lowrank_update(y, t, e.up_w16, M, npad, e.rp, scale)                  # y += s t U^T
-        ctx.cfg, ctx.e, ctx.scale = cfg, e, scale
+        _lowrank_update(y, t, e.up_w16, M, npad, e.rp, scale, drop_p, drop_seed)     # y += s mask (t U^T)
+        ctx.cfg, ctx.e, ctx.scale, ctx.drop = cfg, e, scale, (drop_p, drop_seed)
         ctx.has = (rowbias is not None, residual is not None)
         ctx.save_for_backward(x, t, w_base, rowbias)
         return y
@@ -405,6 +413,7 @@ class _LoraLayer(torch.autograd.Function):
     def backward(ctx, dy):
         x, t, w_base, rowbias = ctx.saved_tensors
         cfg, e, scale = ctx.cfg, ctx.e, ctx.scale
+        drop_p, drop_seed = ctx.drop
         has_rb, has_res = ctx.has
         dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
         M, npad = dy.shape
@@ -413,17 +422,25 @@ class _LoraLayer(torch.autograd.Function):
         drb = None
         if has_rb:
             drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
-        dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)      # dt = dy U (unscaled; `scale` is applied by its consumers)
-        dx = None
         cin_p = e.cin_p
         need_dx = ctx.needs_input_grad[0]
+        g = dy                                       # gradient of the LoRA branch output: mask dy / (1-p) with dropout on
+        if drop_p > 0.0:
+            g = torch.empty_like(dy)
+            launch_gemm_dropmask(dy, g, drop_p, drop_seed)
+        dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)      # dt = g U (unscaled; `scale` is applied by its consumers)
+        dx = None
+        ride = drop_p == 0.0                         # dt can ride in the dx launch only when both read the same dy
+        if not ride:
+            launch_gemm(M=M, N=e.rp, K=npad, A=g.data_ptr(), lda=_ld(g), B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16),
+                        D=dt.data_ptr(), ldd=e.rp)
+        b2 = dict(B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp) if ride else {}
         if need_dx and not conv:
             # linear: [dx | dt] = dy [W^T | U] in ONE launch (dt rides as rp extra output columns)
             wb = prepared_weight(w_base, "bwd")
             dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
-            launch_gemm(M=M, N=cin_p + e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
-                        D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p,
-                        D2=dt.data_ptr(), ldd2=e.rp)
+            launch_gemm(M=M, N=cin_p + (e.rp if ride else 0), K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(),
+                        ldb=wb.shape[1], D=dx.data_ptr(), ldd=cin_p, **b2)
             _lowrank_update(dx, dt, e.down_w16, M, cin_p, e.rp, scale)           # dx += s dt D
         elif need_dx and e.rp <= 32 and _wgrad_window_ok(cfg.fwd_geom(cin_p), M) and cfg.taps() in (3, 9):
             # stride-1 same-size conv: dt = dy U rides in the backward-data launch (rp extra output columns whose weights
@@ -431,15 +448,17 @@ class _LoraLayer(torch.autograd.Function):
             wb = prepared_weight(w_base, "bwd")
             bg = cfg.bwd_geom(npad)
             dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
-            launch_gemm(M=M, N=cin_p + e.rp, K=wb.shape[1], A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1],
-                        D=dx.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=bg, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16),
-                        n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp, b2_k0=(bg.py * bg.KW + bg.px) * npad, b2_klen=npad)
+            if ride:
+                b2.update(b2_k0=(bg.py * bg.KW + bg.px) * npad, b2_klen=npad)
+            launch_gemm(M=M, N=cin_p + (e.rp if ride else 0), K=wb.shape[1], A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(),
+                        ldb=wb.shape[1], D=dx.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=bg, **b2)
             fg = cfg.fwd_geom(cin_p)
             nv.call("t2v_lowrank_window_update", dx.data_ptr(), cin_p, dt.data_ptr(), e.rp, e.down_w16.data_ptr(),
                     cfg.taps() * cin_p, C.byref(fg), M, cin_p, e.rp, scale, nv.stream())
         else:
-            launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16),
-                        D=dt.data_ptr(), ldd=e.rp)
+            if ride:
+                launch_gemm(M=M, N=e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16),
+                            D=dt.data_ptr(), ldd=e.rp)
             if need_dx:
                 wb = prepared_weight(w_base, "bwd")
                 Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
@@ -456,37 +475,9 @@ class _LoraLayer(torch.autograd.Function):
                             nv.stream())
                 else:
                     dx = dxv
-        # factor gradients, accumulated in place in the flat fp32 gradient buffer (side stream: see _side above)
-        kw = cfg.taps() * cin_p
-
-        def wgrads():   # dU = s t^T dy and dD = s dt^T x_col, accumulated into the flat fp32 gradient buffer
-            g = cfg.fwd_geom(cin_p) if conv else None
-            if e.rp <= 32 and x.shape[0] == M and (not conv or _wgrad_window_ok(g, M)):
-                # streaming kernel: dy and x are read once, the window is applied to the rank-wide operand dt
-                w = nv.LoraWgrad()
-                w.rows, w.rp, w.conv = M, e.rp, 1 if conv else 0
-                w.t, w.ldt, w.dy, w.lddy, w.N = t.data_ptr(), _ld(t), dy.data_ptr(), _ld(dy), npad
-                w.dU, w.lddu = e.up_g.data_ptr(), _ld(e.up_g)
-                w.dt, w.lddt, w.x, w.ldx, w.C = dt.data_ptr(), _ld(dt), x.data_ptr(), _ld(x), cin_p
-                w.dD, w.lddd = e.down_g.data_ptr(), kw
-                if conv:
-                    w.geom = g
-                w.alpha = scale
-                nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
-                return
-            launch_gemm_pair(     # strided / resampled windows: two K-major GEMMs in one launch
-                dict(M=e.rp, N=npad, K=M, A=t.data_ptr(), lda=e.rp, a_trans=1, B=dy.data_ptr(), ldb=_ld(dy), b_trans=1,
-                     D=e.up_g.data_ptr(), ldd=_ld(e.up_g), out_mode=nv.OUT_F32_ATOMIC, alpha=scale,
-                     split_k=_split_k((npad + 63) // 64, M)),
-                dict(M=e.rp, N=kw, K=M, A=dt.data_ptr(), lda=e.rp, a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
-                     b_conv=1 if conv else 0, geom=g, D=e.down_g.data_ptr(), ldd=kw,
-                     out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M)))
-
-        if _side["enabled"]:
-            _fork_side(wgrads, (dy, t, dt, x))
-        else:
-            wgrads()
-        return dx, None, None, None, None, drb, dres, None, None, None
+        # factor gradients dU = s t^T g, dD = s dt^T x, accumulated in the flat fp32 gradient buffer (side stream)
+        _lora_side_grads(x, g.data_ptr(), _ld(g), [g, dy, x, t, dt], cfg, e, scale, M, npad, cin_p, t=t, dt=dt)
+        return dx, None, None, None, None, drb, dres, None, None, None, None, None
 
 
 def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=None, dt=None):
@@ -808,8 +799,9 @@ def _wgrad_window_ok(g, rows):
             and g.KH * g.KW in (1, 3, 9) and rows % (g.Hv * g.Wv) == 0)
 
 
-def lora_layer(x, w_base, b_base, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None):
-    return _LoraLayer.apply(x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, entry, float(scale))
+def lora_layer(x, w_base, b_base, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None, drop_p=0.0, drop_seed=0):
+    return _LoraLayer.apply(x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, entry, float(scale), float(drop_p),
+                            int(drop_seed))
 
 
 def conv_linear(x, weight, bias=None, cfg=LINEAR, rowbias=None, residual=None, alpha=1.0, drop_p=0.0, drop_seed=0):

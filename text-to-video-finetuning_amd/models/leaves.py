@@ -80,14 +80,17 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None):
     if base is not None and hasattr(mod, "lora_down") and hasattr(mod, "lora_up"):      # cloneofsimo wrapper
         entry = getattr(mod, "_t2v_bank", None)
         sel = getattr(mod, "selector", None)
-        if (entry is not None and _drop_p(getattr(mod, "dropout", None)) == 0.0 and not base.weight.requires_grad
+        p = _drop_p(getattr(mod, "dropout", None))
+        if (entry is not None and not base.weight.requires_grad
                 and (base.bias is None or not base.bias.requires_grad) and (sel is None or isinstance(sel, nn.Identity))
                 and torch.is_grad_enabled()):
-            if getattr(entry, "merge_scale", None) == float(mod.scale):      # merged weight W + s U D is current for this scale
+            if p == 0.0 and getattr(entry, "merge_scale", None) == float(mod.scale):   # merged weight W + s U D is current
                 return F.lora_merged(x, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry, float(mod.scale),
                                      rowbias, residual)
-            return F.lora_layer(x, base.weight, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry,
-                                float(mod.scale), rowbias, residual)
+            if p == 0.0 or entry.rp in (8, 16, 24, 32, 48, 64, 96):
+                # LoRA branch kept apart from the weight: active dropout (the reference's default train mode), or merge off
+                return F.lora_layer(x, base.weight, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry,
+                                    float(mod.scale), rowbias, residual, drop_p=p, drop_seed=_next_seed() if p > 0 else 0)
         y = F.conv_linear(x, base.weight, base.bias, cfg, rowbias, residual)
         t = F.conv_linear(x, mod.lora_down.weight, None, cfg)
         sel = getattr(mod, "selector", None)
