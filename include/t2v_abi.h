@@ -100,6 +100,10 @@ typedef struct {
    * with few output tiles (partials are accumulated in the scratch, a finalize pass applies the epilogue).
    * ws_split is internal (set 0). */
   void* workspace; size_t workspace_bytes; int ws_split;
+  /* internal (set 0): tile rasterisation chosen by the library — 0: an XCD owns a run of M-tiles x all N-tiles (activation
+   * panels stay in its L2, every XCD streams the whole weight matrix); 1: an XCD owns a run of N-tiles x all M-tiles (each
+   * weight column block is fetched by ONE XCD — the layers whose weights outweigh their activations: 8x8 / 4x4 levels) */
+  int raster_n;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
 /* Tuned tile table: text, one line per problem signature ("M N K a_mode n_split out_mode has_res batch KH KW sy tdiv up C

@@ -229,7 +229,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
     int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = t / ntn, tn = t - tm * ntn;
+  int tm, tn;
+  if (p.raster_n) {            // an XCD's run covers a few N-tiles x all M-tiles: its weight columns are fetched once, by it alone
+    const int ntm = (M + BM - 1) / BM;
+    tn = t / ntm;
+    tm = t - tn * ntm;
+  } else {                     // an XCD's run covers a few M-tiles x all N-tiles: its activation rows stay in its L2
+    tm = t / ntn;
+    tn = t - tm * ntn;
+  }
   const long long m0 = (long long)tm * BM;
   const int n0 = tn * BN;
   const int z = blockIdx.z;
@@ -748,6 +756,16 @@ int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
     split = (p.K + per - 1) / per;              // every split slice is written (no empty K ranges)
   }
   q.ws_split = split > 1 ? split : 0;
+  {
+    // Rasterisation by HBM-side traffic.  Each of the 8 XCDs has its own L2: with M-major runs every XCD streams the whole
+    // weight matrix (8 |B| + |A|), with N-major runs every XCD streams all activations (|B| + 8 |A|).  |A| = unique source
+    // bytes (a 3x3 window re-gathers rows that are already in the L2), |B| = N x K weights.
+    static const int force = [] { const char* e = getenv("T2V_GEMM_RASTER"); return e ? atoi(e) : -1; }();
+    const double bytesA = (double)p.M * (p.a_mode == T2V_A_CONV ? p.geom.C : p.K) * 2.0;
+    const double bytesB = (double)p.N * p.K * 2.0;
+    q.raster_n = force >= 0 ? force : (bytesB + 8.0 * bytesA < bytesA + 8.0 * bytesB ? 1 : 0);
+    if (p.batch > 1) q.raster_n = 0;
+  }
   int rc;
   const bool s2 = c.stages == 2;
   switch (c.tile) {

@@ -57,7 +57,7 @@ class Gemm(C.Structure):
         ("drop_p", c_float), ("drop_seed", c_ull),
         ("B2", c_void_p), ("ldb2", c_ll), ("n_split", c_int), ("D2", c_void_p), ("ldd2", c_ll),
         ("b_tapflip", c_int), ("b2_k0", c_int), ("b2_klen", c_int),
-        ("workspace", c_void_p), ("workspace_bytes", C.c_size_t), ("ws_split", c_int),
+        ("workspace", c_void_p), ("workspace_bytes", C.c_size_t), ("ws_split", c_int), ("raster_n", c_int),
     ]
 
 
