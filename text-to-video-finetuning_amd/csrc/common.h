@@ -14,12 +14,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, through the hardware conversion (v_cvt_pk_bf16_f32 on gfx950: one instruction per
+// pair instead of ~5 integer VALU ops per element — the epilogues and streaming kernels convert every output element)
+typedef __attribute__((ext_vector_type(2))) float t2v_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 t2v_bf16x2;
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  const t2v_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, t2v_bf16x2));
 }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)(pack2bf(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ bf16x8 pack8bf(const float (&v)[8]) {
+  const unsigned a = pack2bf(v[0], v[1]), b = pack2bf(v[2], v[3]), c = pack2bf(v[4], v[5]), d = pack2bf(v[6], v[7]);
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 q = {a, b, c, d};
+  return __builtin_bit_cast(bf16x8, q);
+}
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }

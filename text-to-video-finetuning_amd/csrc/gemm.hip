@@ -73,10 +73,7 @@ __device__ __forceinline__ void finish_chunk(const T2VGemm& p, float (&v)[8], lo
     if (p.n_split > 0 && col >= p.n_split) {     // second output block (LoRA down projection): alpha only, bf16
       bf16_t* dp = (bf16_t*)p.D2 + row * p.ldd2 + (col - p.n_split);
       if (full) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[e]);
-        *(bf16x8*)dp = o;
+        *(bf16x8*)dp = pack8bf(v);
       } else {
         for (int e = 0; e < nv; ++e) dp[e] = f2bf(v[e]);
       }
@@ -90,9 +87,14 @@ __device__ __forceinline__ void finish_chunk(const T2VGemm& p, float (&v)[8], lo
       }
     }
     if (bias) {
+      if (full) {
+        const float4 b0 = *(const float4*)(bias + col), b1 = *(const float4*)(bias + col + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (e < nv) v[e] += bias[col + e];
+        for (int e = 0; e < 8; ++e)
+          if (e < nv) v[e] += bias[col + e];
+      }
     }
     if (rowbias) {
       const bf16_t* rb = rowbias + (row / p.rows_per_rb) * p.ldrb + col;
@@ -122,10 +124,7 @@ __device__ __forceinline__ void finish_chunk(const T2VGemm& p, float (&v)[8], lo
     if (p.out_mode == T2V_OUT_BF16) {
       bf16_t* dp = (bf16_t*)p.D + di;
       if (full) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[e]);
-        *(bf16x8*)dp = o;
+        *(bf16x8*)dp = pack8bf(v);
       } else {
         for (int e = 0; e < nv; ++e) dp[e] = f2bf(v[e]);
       }
@@ -210,7 +209,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // flight across the barrier, so small, latency-bound shapes (most of this UNet at batch 1) no longer serialise on a
 // single prefetch.  LDS image is lane-linear (what the DMA writes); the XOR swizzle is applied to the per-lane
 // SOURCE chunk and to the fragment reads (same involution).  Conv zero padding / edge rows read a zero page.
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+// LEAN = true: the loader of the common case (K % 64 == 0; windowed A: C % 64 == 0, so a K step never straddles a tap; every
+// operand below 2 GiB).  Counters of the first build (SQ_INSTS_VALU : MFMA = 19-24 : 1, SQ_INSTS_SALU 11-16 : 1 on the 128x64
+// tile, profiles/r02_gemm_counters.txt) showed the K loop bound by address arithmetic, not by MFMA or memory: every 16-byte
+// chunk re-derived a 64-bit pointer, its validity and a zero-page select each K step.  Here operands go through buffer
+// descriptors: a row's byte offset is a 32-bit VGPR that changes only when the window moves to the next tap, the K advance is
+// a SCALAR offset shared by the wave, and rows that are padding / out of range carry an out-of-range offset so the hardware
+// bounds check writes the zeros (no zero page, no select).
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
@@ -306,9 +312,86 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
     }
   }
 
+  // ---- lean loader state (LEAN only)
+  constexpr unsigned OOB = 0x80000000u;                 // >= num_records of every descriptor: the load returns zeros
+  unsigned va[NCA], vb[NCB];
+  int sc = 0, sky = 0, skx = 0;                          // scalar position of the NEXT K step inside the window: channel, tap row/col
+  __amdgpu_buffer_rsrc_t srdA, srdB, srdB2;
+  unsigned b2lane = 0;                                   // load i of this WAVE reads rows of the second weight block
+  auto conv_rows = [&]() {                               // byte offsets of this thread's A rows under tap (sky, skx)
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      int vy = rvy[i] + sky, vx = rvx[i] + skx;
+      bool v = aok[i];
+      if (g.tdiv == 2) {
+        v = v && (((vy | vx) & 1) == 0);
+        vy >>= 1;
+        vx >>= 1;
+      }
+      v = v && ((unsigned)vy < (unsigned)g.Hv) && ((unsigned)vx < (unsigned)g.Wv);
+      const unsigned sr = (unsigned)((rn[i] + (vy >> g.up)) * Wr + (vx >> g.up));
+      va[i] = v ? (sr * (unsigned)p.lda + (unsigned)kc * 8u) * 2u : OOB;
+    }
+  };
+  if constexpr (LEAN) {
+    srdA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x80000000u, 0x00020000);
+    srdB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x80000000u, 0x00020000);
+    srdB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.n_split > 0 ? p.B2 : p.B), 0, 0x80000000u, 0x00020000);
+    if (is_conv) {
+      const int tap0 = kbeg / g.C;
+      sc = kbeg - tap0 * g.C;
+      sky = tap0 / g.KW;
+      skx = tap0 - sky * g.KW;
+      conv_rows();
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) {
+        const long long m = m0 + (tid >> 3) + RPP * i;
+        va[i] = aok[i] ? ((unsigned)m * (unsigned)p.lda + (unsigned)kc * 8u) * 2u : OOB;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int n = n0 + (tid >> 3) + RPP * i;
+      // rows of one wave and one i are 8 consecutive n starting at a multiple of 8, and n_split % 8 == 0: wave-uniform side
+      const bool second = p.n_split > 0 && (n0 + (__builtin_amdgcn_readfirstlane(wave) << 3) + RPP * i) >= p.n_split;
+      if (second) b2lane |= 1u << i;
+      const unsigned row = (unsigned)(second ? n - p.n_split : n);
+      vb[i] = bok[i] ? (row * (unsigned)(second ? p.ldb2 : p.ldb) + (unsigned)kc * 8u) * 2u - (second ? (unsigned)wlo * 2u : 0u) : OOB;
+    }
+  }
+
   auto issue = [&](int k0, int stage) {
     unsigned char* sA = smem + stage * STAGE;
     unsigned char* sB = sA + A_BYTES;
+    if constexpr (LEAN) {
+      const int soa = (is_conv ? sc : k0) * 2;           // scalar byte offset of this K step inside the A rows
+#pragma unroll
+      for (int i = 0; i < NCA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(sA + (tid + NT * i) * 16), 16,
+                                                 (int)va[i], soa, 0, 0);
+      const bool win = k0 >= wlo && k0 < whi;            // K steps never straddle the window either (b2_k0, b2_klen % 64 == 0)
+#pragma unroll
+      for (int i = 0; i < NCB; ++i) {
+        const bool second = (b2lane >> i) & 1u;          // wave-uniform
+        const unsigned vo = (second && !win) ? OOB : vb[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? srdB2 : srdB,
+                                                 (__attribute__((address_space(3))) void*)(sB + (tid + NT * i) * 16), 16, (int)vo,
+                                                 k0 * 2, 0, 0);
+      }
+      if (is_conv) {                                     // advance the window position of the next K step
+        sc += BK;
+        if (sc >= g.C) {
+          sc = 0;
+          if (++skx == g.KW) {
+            skx = 0;
+            ++sky;
+          }
+          conv_rows();
+        }
+      }
+      return;
+    }
     const int kidx = k0 + kc * 8;
     const bool kok = kidx < kend;
     if (is_conv) {
@@ -692,12 +775,30 @@ int launch(const T2VGemm& p, hipStream_t s) {
 
 bool g_force_regstage = false;   // T2V_GEMM_REGSTAGE=1: A/B the register-staged mainloop against the LDS-DMA pipeline
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-int launch_dma(const T2VGemm& p, hipStream_t s) {
+bool lean_ok(const T2VGemm& p) {
+  static const int off = [] { const char* e = getenv("T2V_GEMM_LEAN"); return e && e[0] == '0'; }();
+  if (off || p.K % 64 != 0 || p.batch > 1) return false;
+  const long long lim = 0x7ff00000ll;                      // every byte offset (incl. a K step) stays below the 2 GiB record limit
+  if (p.a_mode == T2V_A_CONV) {
+    const T2VConvGeom& g = p.geom;
+    if (g.C % 64 != 0) return false;
+    const long long nimg = ((long long)p.M + (long long)g.Ho * g.Wo - 1) / ((long long)g.Ho * g.Wo);
+    if (nimg * (g.Hv >> g.up) * (g.Wv >> g.up) * p.lda * 2 > lim) return false;
+  } else if ((long long)p.M * p.lda * 2 > lim) {
+    return false;
+  }
+  if ((long long)p.N * p.ldb * 2 > lim) return false;
+  if (p.n_split > 0 && ((long long)(p.N - p.n_split) * p.ldb2 * 2 > lim || p.n_split % 8 != 0)) return false;
+  if (p.b2_klen > 0 && (p.b2_k0 % 64 != 0 || p.b2_klen % 64 != 0)) return false;
+  return true;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN>
+int launch_dma_v(const T2VGemm& p, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BK * 2;
   constexpr int EPI = WM * 32 * BN * 4;
   constexpr int SMEM = RING > EPI ? RING : EPI;
-  auto kern = gemm_kernel_dma<BM, BN, WM, WN, NSTAGE>;
+  auto kern = gemm_kernel_dma<BM, BN, WM, WN, NSTAGE, LEAN>;
   static bool attr_set = false;
   if (!attr_set) {
     if (SMEM > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -708,6 +809,11 @@ int launch_dma(const T2VGemm& p, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), SMEM, s, p);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_dma(const T2VGemm& p, hipStream_t s) {
+  return lean_ok(p) ? launch_dma_v<BM, BN, WM, WN, NSTAGE, true>(p, s) : launch_dma_v<BM, BN, WM, WN, NSTAGE, false>(p, s);
 }
 
 __global__ __launch_bounds__(256) void zero_f32_kernel(float4* p, long long n4) {
