@@ -196,6 +196,107 @@ __device__ __forceinline__ void epilogue(const T2VGemm& p, f32x16 (&acc)[BM / (W
   }
 }
 
+// ---- lean epilogue (bf16 output, no dropout / split-K, N % 8 == 0, every offset below 2^31 — what lean_ok() admits):
+// 32-bit offsets, vector bias, hardware bf16 conversion, and the residual tile PREFETCHED into registers before the K loop
+// (the load latency of `+ R` otherwise sits, un-overlapped, between the barrier-separated passes of the epilogue).
+template <int BM, int BN, int WM, int WN>
+struct EpiPre {
+  static constexpr int NT = WM * WN * 64, FM = BM / (WM * 32), CPR = BN / 8;
+  static constexpr int ITERS = (WM * 32 * CPR + NT - 1) / NT;
+  static constexpr bool PRE = FM * ITERS <= 8;          // register budget: up to 8 x 16 bytes per thread
+  bf16x8 r[PRE ? FM : 1][PRE ? ITERS : 1];
+};
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epi_prefetch(const T2VGemm& p, EpiPre<BM, BN, WM, WN>& pre, long long m0, int n0) {
+  using E = EpiPre<BM, BN, WM, WN>;
+  if constexpr (E::PRE) {
+    const int tid = threadIdx.x;
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < E::FM; ++i)
+#pragma unroll
+      for (int it = 0; it < E::ITERS; ++it) {
+        const int c = tid + E::NT * it;
+        const int rl = c / E::CPR, cc = c - rl * E::CPR;
+        const unsigned row = (unsigned)m0 + (rl >> 5) * (E::FM * 32) + i * 32 + (rl & 31);
+        const int col = n0 + cc * 8;
+        const bool ok = c < WM * 32 * E::CPR && row < (unsigned)p.M && col < p.N && (p.n_split <= 0 || col < p.n_split);
+        pre.r[i][it] = (ok && p.R) ? *(const bf16x8*)((const bf16_t*)p.R + row * (unsigned)p.ldr + col) : z8;
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_lean(const T2VGemm& p, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)],
+                                              unsigned char* smem, long long m0, int n0, const EpiPre<BM, BN, WM, WN>& pre) {
+  using E = EpiPre<BM, BN, WM, WN>;
+  constexpr int NT = E::NT, FM = E::FM, FN = BN / (WN * 32), CPR = E::CPR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  float* sC = (float*)smem;
+  const float* bias = (const float*)p.bias;
+  const bf16_t* rowbias = (const bf16_t*)p.rowbias;
+  const bf16_t* R = (const bf16_t*)p.R;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int cl = wc * (FN * 32) + j * 32 + (lane & 31);
+        sC[rl * BN + cl] = acc[i][j][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < E::ITERS; ++it) {
+      const int c = tid + NT * it;
+      if (c >= WM * 32 * CPR) break;
+      const int rl = c / CPR, cc = c - rl * CPR;
+      const unsigned row = (unsigned)m0 + (rl >> 5) * (FM * 32) + i * 32 + (rl & 31);
+      const int col = n0 + cc * 8;
+      if (row >= (unsigned)p.M || col >= p.N) continue;
+      float v[8];
+      {
+        const float4 a = *(const float4*)(sC + rl * BN + cc * 8);
+        const float4 b = *(const float4*)(sC + rl * BN + cc * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+      if (p.alpha != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+      }
+      if (p.n_split > 0 && col >= p.n_split) {          // rank columns: second output block, alpha only
+        *(bf16x8*)((bf16_t*)p.D2 + row * (unsigned)p.ldd2 + (col - p.n_split)) = pack8bf(v);
+        continue;
+      }
+      if (bias) {
+        const float4 b0 = *(const float4*)(bias + col), b1 = *(const float4*)(bias + col + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (rowbias) {
+        const bf16x8 t = *(const bf16x8*)(rowbias + (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f((unsigned short)t[e]);
+      }
+      if (p.act == T2V_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+      }
+      if (R) {
+        bf16x8 t;
+        if constexpr (E::PRE) t = pre.r[i][it];
+        else t = *(const bf16x8*)(R + row * (unsigned)p.ldr + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.beta * bf2f((unsigned short)t[e]);
+      }
+      *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = pack8bf(v);
+    }
+  }
+}
+
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[64];   // source for predicated-off LDS-DMA lanes (zero padding)
 
 template <int N>
@@ -236,7 +337,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   int tm, tn;
-  if (p.raster_n) {            // an XCD's run covers a few N-tiles x all M-tiles: its weight columns are fetched once, by it alone
+  if (p.raster_n & 1) {        // an XCD's run covers a few N-tiles x all M-tiles: its weight columns are fetched once, by it alone
     const int ntm = (M + BM - 1) / BM;
     tn = t / ntm;
     tm = t - tn * ntm;
@@ -468,6 +569,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
     }
   };
 
+  // lean epilogue conditions beyond lean_ok(): bf16 output, no dropout, no split-K, whole 8-column chunks
+  const bool epi_fast = LEAN && p.out_mode == T2V_OUT_BF16 && p.ws_split <= 1 && p.drop_p == 0.f && (N & 7) == 0 && !(p.raster_n & 2);
+  EpiPre<BM, BN, WM, WN> pre;
+  if constexpr (LEAN) {
+    if (epi_fast) epi_prefetch<BM, BN, WM, WN>(p, pre, m0, n0);      // issued BEFORE the first LDS-DMA: older than every counted load
+  }
   const int nt = (kend - kbeg + BK - 1) / BK;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -489,6 +596,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
   }
   wait_vmcnt<0>();
   __syncthreads();                                               // ring is idle: reuse it for the epilogue staging
+  if constexpr (LEAN) {
+    if (epi_fast) {
+      epilogue_lean<BM, BN, WM, WN>(p, acc, smem, m0, n0, pre);
+      return;
+    }
+  }
   epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, z, zoffD, zoffR);
 }
 
@@ -790,6 +903,9 @@ bool lean_ok(const T2VGemm& p) {
   if ((long long)p.N * p.ldb * 2 > lim) return false;
   if (p.n_split > 0 && ((long long)(p.N - p.n_split) * p.ldb2 * 2 > lim || p.n_split % 8 != 0)) return false;
   if (p.b2_klen > 0 && (p.b2_k0 % 64 != 0 || p.b2_klen % 64 != 0)) return false;
+  // the lean epilogue indexes D, R, D2 and the row-bias with 32-bit element offsets
+  if ((long long)p.M * p.ldd > lim || (p.R && (long long)p.M * p.ldr > lim) || (p.n_split > 0 && (long long)p.M * p.ldd2 > lim)) return false;
+  if (p.rowbias && (long long)(p.M / (p.rows_per_rb > 0 ? p.rows_per_rb : 1) + 1) * p.ldrb > lim) return false;
   return true;
 }
 
@@ -873,6 +989,8 @@ int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
     const double bytesB = (double)p.N * p.K * 2.0;
     q.raster_n = force == 2 ? (bytesB + 8.0 * bytesA < bytesA + 8.0 * bytesB ? 1 : 0) : (force == 1 ? 1 : 0);
     if (p.batch > 1) q.raster_n = 0;
+    static const int no_epi = [] { const char* e = getenv("T2V_GEMM_EPI"); return e && e[0] == '0'; }();   // A/B switch
+    if (no_epi) q.raster_n |= 2;
   }
   int rc;
   const bool s2 = c.stages == 2;
