@@ -458,7 +458,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
       const bool second = p.n_split > 0 && (n0 + (__builtin_amdgcn_readfirstlane(wave) << 3) + RPP * i) >= p.n_split;
       if (second) b2lane |= 1u << i;
       const unsigned row = (unsigned)(second ? n - p.n_split : n);
-      vb[i] = bok[i] ? (row * (unsigned)(second ? p.ldb2 : p.ldb) + (unsigned)kc * 8u) * 2u - (second ? (unsigned)wlo * 2u : 0u) : OOB;
+      vb[i] = bok[i] ? (row * (unsigned)(second ? p.ldb2 : p.ldb) + (unsigned)kc * 8u) * 2u : OOB;   // K window origin: scalar offset below
     }
   }
 
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
         const unsigned vo = (second && !win) ? OOB : vb[i];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? srdB2 : srdB,
                                                  (__attribute__((address_space(3))) void*)(sB + (tid + NT * i) * 16), 16, (int)vo,
-                                                 k0 * 2, 0, 0);
+                                                 (second ? k0 - wlo : k0) * 2, 0, 0);   // offsets add zero-extended: never negative
       }
       if (is_conv) {                                     // advance the window position of the next K step
         sc += BK;
