@@ -276,8 +276,9 @@ int t2v_cast_bf16_to_f32(const void* x, float* y, long long n, int accumulate, t
 /* loss[0] += mean((pred-target)^2); dpred = 2*(pred-target)/n * gscale   (fp32, F.mse_loss) */
 int t2v_mse_fwd_bwd(const float* pred, const float* target, long long n, float* loss, float* dpred, float gscale,
                     t2v_stream_t stream);
-/* out[0] += sum(x^2) over a flat fp32 buffer (global grad-norm, accelerator.clip_grad_norm_) */
-int t2v_sumsq(const float* x, long long n, float* out, t2v_stream_t stream);
+/* out[0] += sum(x^2) over a flat fp32 buffer (global grad-norm, accelerator.clip_grad_norm_).  Fixed-order two-stage
+ * reduction (bit-reproducible: data-parallel replicas must clip identically); workspace: 2048 floats of caller scratch. */
+int t2v_sumsq(const float* x, long long n, float* out, float* workspace, t2v_stream_t stream);
 /* fused AdamW on flat fp32 buffers (torch.optim.AdamW semantics, train.py:238-249,598-604);
  * sumsq: device pointer to sum of squared grads (clip coefficient = min(1, max_norm/(sqrt(sumsq)+1e-6))) or NULL;
  * grads are scaled by grad_scale first (1/world_size after a SUM all-reduce). step = 1-based device counter incremented here. */

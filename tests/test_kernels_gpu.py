@@ -426,6 +426,7 @@ def test_sumsq_adamw_match_torch_optim(n, max_norm, world):
     opt = torch.optim.AdamW([pr], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
     p = p0.clone().cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
     step = torch.zeros(1, dtype=torch.int32, device="cuda"); ss = torch.zeros(1, device="cuda")
+    ws = torch.zeros(2048, device="cuda")
     for it in range(4):
         grad = torch.randn(n, generator=g) * (10.0 if it == 1 else 0.01)       # one step far above the clip threshold
         pr.grad = (grad / world).clone()
@@ -435,7 +436,10 @@ def test_sumsq_adamw_match_torch_optim(n, max_norm, world):
         gd = grad.cuda()
         ss.zero_()
         if max_norm > 0:
-            nv.call("t2v_sumsq", gd.data_ptr(), n, ss.data_ptr(), nv.stream())
+            nv.call("t2v_sumsq", gd.data_ptr(), n, ss.data_ptr(), ws.data_ptr(), nv.stream())
+            ss2 = torch.zeros(1, device="cuda")
+            nv.call("t2v_sumsq", gd.data_ptr(), n, ss2.data_ptr(), ws.data_ptr(), nv.stream())
+            assert torch.equal(ss, ss2)                                  # fixed-order reduction: bit-reproducible
             # the kernel clips the SCALED gradient: sumsq is taken after the all-reduce, before the 1/world scale
             assert abs(ss.sqrt().item() / world - total.item()) < 1e-4 * total.item()
         nv.call("t2v_adamw", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps, wd,
@@ -519,6 +523,23 @@ def test_lora_wrappers_all_kinds_match_reference_golden(fused):
                 _cl(yr).backward(dy[:, : yr.shape[1]].float())
                 dxr = _cl(xr.grad)
             assert relerr(xm.grad[:, : dxr.shape[1]].float(), dxr) < 3e-2, (name, "dx")
+            # factor gradients of the fused node (dt rides in the backward-data launch; K-window of the rank columns for
+            # windowed layers) against autograd of the reference expression
+            wdr, wur = wd.clone().requires_grad_(), wu.clone().requires_grad_()
+            xr2 = xq.float()
+            if name.startswith("linear"):
+                yr2 = TF2.linear(TF2.linear(xr2, wdr), wur) * it["scale"]
+                yr2.reshape(-1, yr2.shape[-1]).backward(dy[:, : yr2.shape[-1]].float())
+            elif name == "conv3d":
+                yr2 = TF2.conv3d(TF2.conv3d(xr2, wdr, padding=(1, 0, 0)), wur) * it["scale"]
+                yr2.permute(0, 2, 3, 4, 1).reshape(dy.shape[0], -1).backward(dy[:, : yr2.shape[1]].float())
+            else:
+                yr2 = TF2.conv2d(TF2.conv2d(xr2, wdr, stride=s_, padding=p_), wur) * it["scale"]
+                _cl(yr2).backward(dy[:, : yr2.shape[1]].float())
+            torch.cuda.synchronize()
+            assert float(wdr.grad.norm()) > 0 and float(wur.grad.norm()) > 0
+            assert relerr(mod.lora_up.weight.grad.float(), wur.grad) < 3e-2, (name, "dU")
+            assert relerr(mod.lora_down.weight.grad.float(), wdr.grad) < 3e-2, (name, "dD")
 
 
 @pytest.mark.parametrize("Np,Cp,taps,rp,grouped", [(320, 320, 1, 16, False), (72, 40, 9, 8, False), (128, 64, 3, 32, False),

@@ -408,14 +408,28 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
   if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+// Two fixed-order stages (no floating-point atomics): every data-parallel replica must derive the SAME clip coefficient from
+// the same reduced gradient, bit for bit — an atomic sum differs in its last bits between ranks and lets the replicas drift.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ partial) {
   __shared__ float red[4];
   float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += x[i] * x[i];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];      // thread t: partials t, t+256, ... in index order
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += red[0];
 }
 
 // torch.optim.AdamW (decoupled weight decay, bias correction, eps outside the sqrt of v_hat)
@@ -590,9 +604,12 @@ extern "C" int t2v_mse_fwd_bwd(const float* pred, const float* target, long long
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
-extern "C" int t2v_sumsq(const float* x, long long n, float* out, t2v_stream_t s) {
-  T2V_CHECK_ARG(x && out && n > 0, "t2v_sumsq: bad args");
-  hipLaunchKernelGGL(sumsq_kernel, dim3((int)max(1LL, min((n + 255) / 256, 2048LL))), dim3(256), 0, (hipStream_t)s, x, n, out);
+extern "C" int t2v_sumsq(const float* x, long long n, float* out, float* workspace, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && out && workspace && n > 0, "t2v_sumsq: bad args (workspace: 2048 floats)");
+  const int nb = (int)max(1LL, min((n + 255) / 256, 2048LL));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, x, n, workspace);
+  T2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nb, out);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

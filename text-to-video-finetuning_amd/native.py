@@ -132,7 +132,7 @@ SYMBOLS = {
     "t2v_cast_f32_to_bf16": ([c_void_p, c_void_p, c_ll, c_void_p], c_int),
     "t2v_cast_bf16_to_f32": ([c_void_p, c_void_p, c_ll, c_int, c_void_p], c_int),
     "t2v_mse_fwd_bwd": ([c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_float, c_void_p], c_int),
-    "t2v_sumsq": ([c_void_p, c_ll, c_void_p, c_void_p], c_int),
+    "t2v_sumsq": ([c_void_p, c_ll, c_void_p, c_void_p, c_void_p], c_int),
     "t2v_adamw": ([c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float, c_void_p,
                    c_float, c_float, c_void_p, c_void_p], c_int),
 }

@@ -85,6 +85,7 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sumsq_ws = torch.zeros(2048, dtype=torch.float32, device=dev)
         off, offsets = 0, {}
         self._homes = []
         for p, k in zip(plist, sizes):
@@ -140,7 +141,7 @@ class FlatAdamW:
         self.sumsq.zero_()
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         if clip:
-            nv.call("t2v_sumsq", self.flat_g.data_ptr(), self.numel, self.sumsq.data_ptr(), s)
+            nv.call("t2v_sumsq", self.flat_g.data_ptr(), self.numel, self.sumsq.data_ptr(), self._sumsq_ws.data_ptr(), s)
         nv.call("t2v_adamw", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                 self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 self.sumsq.data_ptr() if clip else None, float(self.max_grad_norm or 0.0), float(grad_scale),
