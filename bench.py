@@ -139,7 +139,10 @@ def gemm_roofline(trainer, batch):
         if geom is not None and geom.tdiv == 2:
             flops /= 4.0                                 # 3/4 of the gathered taps are structural zeros
         nn_kernel = not kw.get("a_trans", 0) and not kw.get("b_trans", 0)
-        records.append((flops, s, e, nn_kernel))
+        # algorithmic bytes: un-replicated input once + output once + weights once
+        taps_ = (geom.KH * geom.KW) if geom is not None else 1
+        abytes = (kw["M"] * (kw["K"] // taps_) + kw["M"] * kw["N"] + kw["N"] * kw["K"]) * 2.0 * z
+        records.append((flops, s, e, nn_kernel, abytes))
         shapes.append(((kw["M"], kw["N"], kw["K"], z, "conv" if geom is not None else "lin",
                         "nn" if nn_kernel else "tn"), flops, s, e))
         if nn_kernel and geom is not None and geom.KH == 3 and geom.KW == 1:
@@ -154,7 +157,7 @@ def gemm_roofline(trainer, batch):
         s.record()
         orig_pair(kw_a, kw_b)
         e.record()
-        records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False))
+        records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False, 0.0))
 
     conv3d, attn, wgrad, shapes, norms = [], [], [], [], []
     nv = F.nv
@@ -212,7 +215,8 @@ def gemm_roofline(trainer, batch):
     out = {}
     for name, sel in (("nn", True), ("kmajor", False)):
         rs = [r for r in records if r[3] == sel]
-        out[name] = dict(launches=len(rs), flops=sum(r[0] for r in rs), ms=sum(r[1].elapsed_time(r[2]) for r in rs))
+        out[name] = dict(launches=len(rs), flops=sum(r[0] for r in rs), ms=sum(r[1].elapsed_time(r[2]) for r in rs),
+                         abytes=sum(r[4] for r in rs))
 
     def both_roofs(flops, nbytes, ms, launches):
         t = ms * 1e-3
@@ -255,13 +259,17 @@ def gemm_roofline(trainer, batch):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the family's heaviest single shape, from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_gemm_conv_l0.json; PMC collection is a separate, slow run — never part of the timed bench)."""
+    """HBM-side bytes per launch of the dominant kernel family in the step AS IT RUNS (every tile the shipped table selects),
+    from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r02_pmc_step.json: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE, separate passes; PMC collection is slow and never part of the timed bench)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_conv_l0.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_step.json")) as f:
             j = json.load(f)
-        return {"shape": "conv3x3 M=32768 N=320 K=2880 (stacked passes, 32x32 level)", "hbm_bytes_per_launch": j["hbm_bytes_per_launch"],
-                "algorithmic_bytes_per_launch": j["algorithmic_bytes_per_launch"], "source": "profiles/r01_pmc_gemm_conv_l0.json"}
+        fam = next(v for k, v in j["families"].items() if k.startswith("gemm_kernel_dma"))
+        return {"kernel_family": "gemm_kernel_dma<...>: all forward / backward-data launches of one C2 step",
+                "hbm_bytes_per_launch": fam["hbm_bytes_per_launch"], "hbm_GB_per_step": fam["hbm_GB_per_step"],
+                "launches_per_step": fam["launches_per_step"], "fetch_correction": j["fetch_correction"],
+                "source": "profiles/r02_pmc_step.json"}
     except Exception:   # noqa: BLE001
         return None
 
@@ -441,7 +449,8 @@ def main():
                     achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     launches=rr["launches"], algorithmic_gflop_per_step=round(rr["flops"] / 1e9, 1),
                     kernel_ms_per_step=round(rr["ms"], 2), traffic=(pmc_traffic() or {}).get("hbm_bytes_per_launch"),
-                    traffic_detail=pmc_traffic(),
+                    algorithmic_bytes_per_launch=int(rr["abytes"] / max(1, rr["launches"])),
+                    algorithmic_GB_per_step=round(rr["abytes"] / 1e9, 2), traffic_detail=pmc_traffic(),
                     secondary={"kernel": "gemm_kernel<..,AT|BT> - K-major / transposed-operand launches (factor gradients of strided convs, "
                                          "VAE attention P.V); the LoRA factor gradients proper are north_star_kernels.lora_factor_gradients",
                                "launches": km["launches"], "algorithmic_gflop_per_step": round(km["flops"] / 1e9, 1),
