@@ -204,11 +204,14 @@ def gemm_roofline(trainer, batch):
     F.launch_gemm = timed
     F.launch_gemm_pair = timed_pair
     nv.call = timed_call
-    try:
+    side_was = F._side["enabled"]
+    F._side["enabled"] = False        # one stream for the instrumented pass: an event pair on the side stream would also count
+    try:                              # the time its kernel waits for the main stream's kernels to leave the CUs
         trainer.opt.zero_grad()
         trainer._fwd_bwd(batch)
         torch.cuda.synchronize()
     finally:
+        F._side["enabled"] = side_was
         F.launch_gemm = orig
         F.launch_gemm_pair = orig_pair
         nv.call = orig_call
