@@ -151,7 +151,11 @@ def _sdpa_ref(q, k, v, heads):
     return (p @ vh).transpose(1, 2).reshape(nb, Sq, heads * 64)
 
 
-@pytest.mark.parametrize("nb,heads,Sq,Sk", [(3, 2, 40, 40), (2, 5, 256, 256), (4, 1, 33, 77), (2, 3, 1024, 1024), (5, 2, 16, 16)])
+# Sq >= 128 / Sk >= 128 take the workgroup kernels (4 waves sharing K|V resp. Q|dO tiles through LDS): whole tiles (256, 1024),
+# ragged query and key blocks (200, 130), long queries against the 77 text keys, and the C4 / C5 spatial sequence lengths
+# (40x72 = 2880, 72x128 = 9216)
+@pytest.mark.parametrize("nb,heads,Sq,Sk", [(3, 2, 40, 40), (2, 5, 256, 256), (4, 1, 33, 77), (2, 3, 1024, 1024), (5, 2, 16, 16),
+                                            (2, 2, 200, 130), (3, 1, 320, 77), (1, 2, 2880, 2880), (1, 1, 9216, 9216)])
 def test_attention_spatial(nb, heads, Sq, Sk):
     import t2v_amd.functional as F
     g = torch.Generator().manual_seed(nb + heads + Sq + Sk)

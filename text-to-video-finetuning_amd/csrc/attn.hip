@@ -12,6 +12,8 @@
 //   dKdV: S = Q K^T (lane = key), dV^T += dO^T P, dK^T += Q^T dS with Q^T/dO^T via transpose reads.
 // Strided operands (t2v_abi.h, T2VAttnOperand) let the same kernel serve temporal attention over frames
 // (sequence stride = H*W*C), per-frame spatial attention and text cross-attention without any permute copy.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -294,6 +296,307 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Workgroup variants (long sequences: spatial self-attention S = H*W >= 128, its text cross-attention):  4 wave64 share the
+// streamed tiles through LDS.  A workgroup owns 128 consecutive queries (fwd, dQ) or keys (dK/dV) of one (batch, head) —
+// one 32-row block per wave, register layouts exactly as in the one-wave kernels above — and the OTHER sequence is staged
+// in 64-row tile pairs (K|V, or Q|dO) by all 256 threads: each row is fetched from memory once per WORKGROUP instead of
+// once per wave (4x less L2 traffic, no per-wave load latency), double-buffered with the fetch of tile t+1 issued before the
+// math of tile t and written to the other LDS stage after it (one barrier per tile).
+constexpr int WG_ROWS = 64;                      // staged rows per tile
+struct __attribute__((aligned(16))) StagePair {
+  bf16_t a[WG_ROWS * LDT];
+  bf16_t b[WG_ROWS * LDT];
+};
+struct PairRegs {
+  bf16x8 a[2], b[2];
+};
+// thread t: rows (t >> 3) and (t >> 3) + 32, 16-byte chunk (t & 7)
+__device__ __forceinline__ void pair_fetch(PairRegs& r, const bf16_t* A, long long sa, const bf16_t* B, long long sb, int row0,
+                                           int rmax, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = row0 + (tid >> 3) + 32 * i;
+    const bool ok = row < rmax;
+    r.a[i] = ldg8(A + (long long)row * sa + (tid & 7) * 8, ok);
+    r.b[i] = ldg8(B + (long long)row * sb + (tid & 7) * 8, ok);
+  }
+}
+__device__ __forceinline__ void pair_store(StagePair& st, const PairRegs& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    *(bf16x8*)(st.a + row * LDT + (tid & 7) * 8) = r.a[i];
+    *(bf16x8*)(st.b + row * LDT + (tid & 7) * 8) = r.b[i];
+  }
+}
+// MFMA operand fragments of tile rows [32*blk, 32*blk+32) (rows = lanes, k = features): what load_row_frags gives from memory
+__device__ __forceinline__ void lds_row_frags(bf16x8 (&f)[4], const bf16_t* s, int blk, int lane) {
+  const bf16_t* row = s + (32 * blk + (lane & 31)) * LDT + 8 * (lane >> 5);
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) f[kd] = *(const bf16x8*)(row + 16 * kd);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
+  __shared__ StagePair st[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  bf16_t* O = (bf16_t*)p.o.ptr + op_off(p.o, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const bool qok = q < Sq;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) qf[kd] = ldg8(Q + (long long)q * p.q.sstride + 16 * kd + 8 * hi, qok);
+  const float c = p.scale * 1.44269504088896341f;          // softmax in base 2: exp(s*scale - m) = exp2(s*c - m*c)
+  float m = -INFINITY, l = 0.f;                             // m: running max of the RAW scores
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+  PairRegs nx;
+  pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, 0, Sk, tid);
+  pair_store(st[0], nx, tid);
+  __syncthreads();
+  const int ntile = (Sk + WG_ROWS - 1) / WG_ROWS;
+  for (int t = 0; t < ntile; ++t) {
+    const StagePair& cur = st[t & 1];
+    if (t + 1 < ntile) pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, (t + 1) * WG_ROWS, Sk, tid);
+    const int kt0 = t * WG_ROWS;
+    const bool ragged = kt0 + WG_ROWS > Sk;                 // workgroup-uniform: only the last tile masks keys
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kt0 + 32 * kb >= Sk) break;
+      bf16x8 kf[4];
+      lds_row_frags(kf, cur.a, kb, lane);
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 4; ++kd) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kd], qf[kd], s, 0, 0, 0);
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt0 + 32 * kb + crow(r, hi) >= Sk) s[r] = -INFINITY;
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mn = fmaxf(m, mx);
+      const float mc = mn * c;
+      const float alpha = exp2f(m * c - mc);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(fmaf(s[r], c, -mc));
+        s[r] = pv;
+        rs += pv;
+      }
+      rs += __shfl_xor(rs, 32);
+      l = l * alpha + rs;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
+      const bf16_t* sv = cur.b + 32 * kb * LDT;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 pb = pack8(s, kk);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sv, 0, kk, lane), pb, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sv, 1, kk, lane), pb, o1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntile) pair_store(st[(t + 1) & 1], nx, tid);
+    __syncthreads();
+  }
+  if (qok) {
+    store_rowT(O, p.o.sstride, q, o0, o1, 1.f / l, hi);
+    if (hi == 0 && p.lse) p.lse[((long long)b * p.heads + h) * Sq + q] = m * p.scale + __logf(l);
+  }
+}
+
+// dQ (and delta = rowsum(dO * O)); workgroup = 128 queries, K|V tiles shared
+__global__ __launch_bounds__(256) void attn_bwd_dq_wg_kernel(const T2VAttn p) {
+  __shared__ StagePair st[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  const bf16_t* O = (const bf16_t*)p.o.ptr + op_off(p.o, b, h);
+  const bf16_t* dO = (const bf16_t*)p.d_o.ptr + op_off(p.d_o, b, h);
+  bf16_t* dQ = (bf16_t*)p.dq.ptr + op_off(p.dq, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const bool qok = q < Sq;
+  bf16x8 qf[4], dof[4];
+  float dl = 0.f;
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) {
+    qf[kd] = ldg8(Q + (long long)q * p.q.sstride + 16 * kd + 8 * hi, qok);
+    dof[kd] = ldg8(dO + (long long)q * p.d_o.sstride + 16 * kd + 8 * hi, qok);
+    const bf16x8 of = ldg8(O + (long long)q * p.o.sstride + 16 * kd + 8 * hi, qok);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += bf2f((unsigned short)of[e]) * bf2f((unsigned short)dof[kd][e]);
+  }
+  dl += __shfl_xor(dl, 32);
+  const long long sidx = ((long long)b * p.heads + h) * Sq + q;
+  if (qok && hi == 0) p.delta[sidx] = dl;
+  const float c = p.scale * 1.44269504088896341f;
+  const float lse2 = qok ? p.lse[sidx] * 1.44269504088896341f : 0.f;      // p = exp2(s*c - lse*log2e)
+  f32x16 a0, a1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
+  PairRegs nx;
+  pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, 0, Sk, tid);
+  pair_store(st[0], nx, tid);
+  __syncthreads();
+  const int ntile = (Sk + WG_ROWS - 1) / WG_ROWS;
+  for (int t = 0; t < ntile; ++t) {
+    const StagePair& cur = st[t & 1];
+    if (t + 1 < ntile) pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, (t + 1) * WG_ROWS, Sk, tid);
+    const int kt0 = t * WG_ROWS;
+    const bool ragged = kt0 + WG_ROWS > Sk;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kt0 + 32 * kb >= Sk) break;
+      bf16x8 kf[4], vf[4];
+      lds_row_frags(kf, cur.a, kb, lane);
+      lds_row_frags(vf, cur.b, kb, lane);
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 4; ++kd) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kd], qf[kd], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kd], dof[kd], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = exp2f(fmaf(s[r], c, -lse2));
+        if (ragged && kt0 + 32 * kb + crow(r, hi) >= Sk) pv = 0.f;
+        s[r] = pv * (dp[r] - dl) * p.scale;
+      }
+      const bf16_t* sk = cur.a + 32 * kb * LDT;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 db = pack8(s, kk);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sk, 0, kk, lane), db, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sk, 1, kk, lane), db, a1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntile) pair_store(st[(t + 1) & 1], nx, tid);
+    __syncthreads();
+  }
+  if (qok) store_rowT(dQ, p.dq.sstride, q, a0, a1, 1.f, hi);
+}
+
+// dK, dV; workgroup = 128 keys, Q|dO tiles (+ their lse / delta rows) shared
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_wg_kernel(const T2VAttn p) {
+  __shared__ StagePair st[2];
+  __shared__ float sL[2][WG_ROWS], sDl[2][WG_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  const bf16_t* dO = (const bf16_t*)p.d_o.ptr + op_off(p.d_o, b, h);
+  bf16_t* dK = (bf16_t*)p.dk.ptr + op_off(p.dk, b, h);
+  bf16_t* dV = (bf16_t*)p.dv.ptr + op_off(p.dv, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  const bool kok = key < Sk;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) {
+    kf[kd] = ldg8(K + (long long)key * p.k.sstride + 16 * kd + 8 * hi, kok);
+    vf[kd] = ldg8(V + (long long)key * p.v.sstride + 16 * kd + 8 * hi, kok);
+  }
+  const float* lsep = p.lse + ((long long)b * p.heads + h) * Sq;
+  const float* dlp = p.delta + ((long long)b * p.heads + h) * Sq;
+  const float c = p.scale * 1.44269504088896341f;
+  f32x16 k0, k1, v0, v1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) k0[r] = k1[r] = v0[r] = v1[r] = 0.f;
+  PairRegs nx;
+  float nl = 0.f, nd = 0.f;                                 // threads 0..63 carry the tile's lse (base 2) / delta rows
+  auto fetch_rows = [&](int row0) {
+    if (tid < WG_ROWS) {
+      const int qr = row0 + tid;
+      nl = qr < Sq ? lsep[qr] * 1.44269504088896341f : 0.f;
+      nd = qr < Sq ? dlp[qr] : 0.f;
+    }
+  };
+  pair_fetch(nx, Q, p.q.sstride, dO, p.d_o.sstride, 0, Sq, tid);
+  fetch_rows(0);
+  pair_store(st[0], nx, tid);
+  if (tid < WG_ROWS) {
+    sL[0][tid] = nl;
+    sDl[0][tid] = nd;
+  }
+  __syncthreads();
+  const int ntile = (Sq + WG_ROWS - 1) / WG_ROWS;
+  for (int t = 0; t < ntile; ++t) {
+    const StagePair& cur = st[t & 1];
+    if (t + 1 < ntile) {
+      pair_fetch(nx, Q, p.q.sstride, dO, p.d_o.sstride, (t + 1) * WG_ROWS, Sq, tid);
+      fetch_rows((t + 1) * WG_ROWS);
+    }
+    const int qt0 = t * WG_ROWS;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if (qt0 + 32 * qb >= Sq) break;
+      bf16x8 qa[4], da[4];
+      lds_row_frags(qa, cur.a, qb, lane);
+      lds_row_frags(da, cur.b, qb, lane);
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 4; ++kd) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kd], kf[kd], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[kd], vf[kd], dp, 0, 0, 0);
+      }
+      f32x16 pr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = 32 * qb + crow(r, hi);
+        const bool ok = (qt0 + ql < Sq) && kok;
+        const float pv = ok ? exp2f(fmaf(s[r], c, -sL[t & 1][ql])) : 0.f;
+        pr[r] = pv;
+        s[r] = pv * (dp[r] - sDl[t & 1][ql]) * p.scale;
+      }
+      const bf16_t* sq = cur.a + 32 * qb * LDT;
+      const bf16_t* sd = cur.b + 32 * qb * LDT;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 pb = pack8(pr, kk), db = pack8(s, kk);
+        v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sd, 0, kk, lane), pb, v0, 0, 0, 0);
+        v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sd, 1, kk, lane), pb, v1, 0, 0, 0);
+        k0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sq, 0, kk, lane), db, k0, 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sq, 1, kk, lane), db, k1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntile) {
+      pair_store(st[(t + 1) & 1], nx, tid);
+      if (tid < WG_ROWS) {
+        sL[(t + 1) & 1][tid] = nl;
+        sDl[(t + 1) & 1][tid] = nd;
+      }
+    }
+    __syncthreads();
+  }
+  if (kok) {
+    store_rowT(dK, p.dk.sstride, key, k0, k1, 1.f, hi);
+    store_rowT(dV, p.dv.sstride, key, v0, v1, 1.f, hi);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Short self-attention sequences (S = Sq = Sk <= 16, S | 32: the temporal attention over F frames): P = 32/S sequences
 // of consecutive batches are packed into ONE 32-row tile — lane&31 = packed row = (sequence lane/S, position lane%S) —
 // and the 32x32 score tile is block-diagonal-masked.  Every lane does useful work (a lone S=16 sequence would idle half
@@ -468,6 +771,12 @@ __host__ inline int packed_seqs(const T2VAttn& p) {
   return 32 / p.Sq;
 }
 
+// workgroup variants pay when the workgroup's 128 rows are (mostly) real: sequences of at least 128
+bool use_wg(int rows) {
+  static const int off = [] { const char* e = getenv("T2V_ATTN_WG"); return e && e[0] == '0'; }();
+  return !off && rows >= 128;
+}
+
 int check_op(const char* fn, const char* name, const T2VAttnOperand& o) {
   if (!o.ptr || o.bdiv <= 0 || ((uintptr_t)o.ptr & 15) || (o.sstride % 8) || (o.bstride_hi % 8) || (o.bstride_lo % 8)) {
     t2v_set_error("%s: operand %s invalid (ptr %p, bdiv %d, strides must be multiples of 8 elements)", fn, name, o.ptr,
@@ -494,6 +803,11 @@ extern "C" int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream) {
   dim3 grid((p->Sq + 31) / 32, p->heads, p->nbatch);
   T2V_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "t2v_attn_fwd: heads/nbatch exceed grid limits (%d, %d)", p->heads,
                 p->nbatch);
+  if (use_wg(p->Sq)) {               // long query sequences: 4 waves share the K|V tiles through LDS
+    hipLaunchKernelGGL(attn_fwd_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+  }
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
@@ -515,10 +829,16 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
   }
   T2V_CHECK_ARG(p->heads <= 65535 && p->nbatch <= 65535, "t2v_attn_bwd: heads/nbatch exceed grid limits");
   dim3 gq((p->Sq + 31) / 32, p->heads, p->nbatch);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
+  if (use_wg(p->Sq))
+    hipLaunchKernelGGL(attn_bwd_dq_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+  else
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   dim3 gk((p->Sk + 31) / 32, p->heads, p->nbatch);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);
+  if (use_wg(p->Sk))
+    hipLaunchKernelGGL(attn_bwd_dkdv_wg_kernel, dim3((p->Sk + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+  else
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
