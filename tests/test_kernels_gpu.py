@@ -642,3 +642,23 @@ def test_fused_lora_dropout_matches_the_unfused_masked_path(kind):
     mod.dropout.p = 0.0
     y0 = run_layer(mod, x.clone().requires_grad_(True), cfg)
     assert relerr(y0, yb) > 1e-3
+
+
+def test_attention_deferred_rescale_branch():
+    """The workgroup forward keeps its running maximum while no row's maximum grows by more than 2^6 and rescales O / l only
+    then.  Random data rarely takes the rescale after the first block; this input FORCES it late and unevenly: a few key rows
+    in the middle and at the end of the sequence are spiked against a few query rows (scores far above everything before),
+    other rows never rescale.  Full-tensor comparison against the fp32 reference."""
+    import t2v_amd.functional as F
+    g = torch.Generator().manual_seed(17)
+    nb, heads, S = 2, 2, 512
+    C = heads * 64
+    q = torch.randn(nb, S, C, generator=g); k = torch.randn(nb, S, C, generator=g); v = torch.randn(nb, S, C, generator=g)
+    for (qi, ki, amp) in ((5, 300, 6.0), (5, 500, 9.0), (130, 70, 8.0), (257, 511, 7.0), (400, 33, 5.0)):
+        k[:, ki, :64] = q[:, qi, :64] * amp / 8.0          # q.k / 8 ~ amp * |q|^2 / 64: dominates the row from key ki on
+    q, k, v = _bf(q), _bf(k), _bf(v)
+    ref = _sdpa_ref(q.float(), k.float(), v.float(), heads)
+    o = F.attention(q.view(-1, C).cuda(), k.view(-1, C).cuda(), v.view(-1, C).cuda(), heads, F.SeqLayout(nb, S, S, 0, 1),
+                    F.SeqLayout(nb, S, S, 0, 1))
+    assert relerr(o, ref.view(-1, C)) < TOL
+    assert float((o.float().cpu() - ref.view(-1, C)).abs().max()) < 0.06

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
   dl += __shfl_xor(dl, 32);
   const long long sidx = ((long long)b * p.heads + h) * Sq + q;
   if (qok && hi == 0) p.delta[sidx] = dl;
-  const float lse = qok ? p.lse[sidx] : 0.f;
+  const float c = p.scale * 1.44269504088896341f;                        // p = exp2(s*c - lse*log2e)
+  const float lse2 = qok ? p.lse[sidx] * 1.44269504088896341f : 0.f;
   f32x16 a0, a1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
@@ -204,9 +205,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kd], dof[kd], dp, 0, 0, 0);
     }
     frags_to_lds(sK, kf, lane);
+    const bool ragged = kt + 32 > Sk;                                     // wave-uniform: only the last tile masks keys
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float pv = (kt + crow(r, hi) < Sk) ? __expf(s[r] * p.scale - lse) : 0.f;
+      float pv = exp2f(fmaf(s[r], c, -lse2));
+      if (ragged && kt + crow(r, hi) >= Sk) pv = 0.f;
       s[r] = pv * (dp[r] - dl) * p.scale;
     }
 #pragma unroll
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
   }
   const float* lsep = p.lse + ((long long)b * p.heads + h) * Sq;
   const float* dlp = p.delta + ((long long)b * p.heads + h) * Sq;
+  const float c = p.scale * 1.44269504088896341f;
   f32x16 k0, k1, v0, v1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) k0[r] = k1[r] = v0[r] = v1[r] = 0.f;
@@ -274,9 +278,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
     for (int r = 0; r < 16; ++r) {
       const int qr = qt + crow(r, hi);
       const bool ok = (qr < Sq) && kok;
-      const float L = ok ? lsep[qr] : 0.f;
+      const float L = ok ? lsep[qr] * 1.44269504088896341f : 0.f;
       const float D = ok ? dlp[qr] : 0.f;
-      float pv = ok ? __expf(s[r] * p.scale - L) : 0.f;
+      float pv = ok ? exp2f(fmaf(s[r], c, -L)) : 0.f;
       pr[r] = pv;
       s[r] = pv * (dp[r] - D) * p.scale;
     }
@@ -384,9 +388,22 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mn = fmaxf(m, mx);
-      const float mc = mn * c;
-      const float alpha = exp2f(m * c - mc);
+      // deferred rescale: as long as no row's maximum grew by more than DEFER (in exponent units) the running maximum is
+      // kept — p <= 2^DEFER instead of <= 1, exact in fp32/bf16 relative terms — and the 32 multiplies of O are skipped.
+      // The decision is taken BEFORE this block's P is exponentiated and covers everything accumulated so far (O and l).
+      constexpr float DEFER = 6.f;
+      if (!__all((mx - m) * c <= DEFER)) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f((m - mn) * c);            // m = -inf on the first block: alpha = 0, O and l are still 0
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          o0[r] *= alpha;
+          o1[r] *= alpha;
+        }
+      }
+      const float mc = m * c;
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -395,13 +412,7 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
         rs += pv;
       }
       rs += __shfl_xor(rs, 32);
-      l = l * alpha + rs;
-      m = mn;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o0[r] *= alpha;
-        o1[r] *= alpha;
-      }
+      l += rs;
       const bf16_t* sv = cur.b + 32 * kb * LDT;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -777,6 +788,15 @@ bool use_wg(int rows) {
   return !off && rows >= 128;
 }
 
+// The backward workgroup kernels read BOTH MFMA operands of the streamed tile from LDS (row-major fragments + transposed
+// fragments: 2x the LDS instructions of the one-wave kernels, which take the row-major fragments straight from memory) and
+// measured 15-20 % slower at S = 2880 / 9216 (scripts/attn_bench.py): LDS-read-bound.  They stay selectable
+// (T2V_ATTN_WG_BWD=1) and tested; the default backward is the one-wave pair.
+bool use_wg_bwd(int rows) {
+  static const int on = [] { const char* e = getenv("T2V_ATTN_WG_BWD"); return e && e[0] == '1'; }();
+  return on && rows >= 128;
+}
+
 int check_op(const char* fn, const char* name, const T2VAttnOperand& o) {
   if (!o.ptr || o.bdiv <= 0 || ((uintptr_t)o.ptr & 15) || (o.sstride % 8) || (o.bstride_hi % 8) || (o.bstride_lo % 8)) {
     t2v_set_error("%s: operand %s invalid (ptr %p, bdiv %d, strides must be multiples of 8 elements)", fn, name, o.ptr,
@@ -829,13 +849,13 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
   }
   T2V_CHECK_ARG(p->heads <= 65535 && p->nbatch <= 65535, "t2v_attn_bwd: heads/nbatch exceed grid limits");
   dim3 gq((p->Sq + 31) / 32, p->heads, p->nbatch);
-  if (use_wg(p->Sq))
+  if (use_wg_bwd(p->Sq))
     hipLaunchKernelGGL(attn_bwd_dq_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   dim3 gk((p->Sk + 31) / 32, p->heads, p->nbatch);
-  if (use_wg(p->Sk))
+  if (use_wg_bwd(p->Sk))
     hipLaunchKernelGGL(attn_bwd_dkdv_wg_kernel, dim3((p->Sk + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);
