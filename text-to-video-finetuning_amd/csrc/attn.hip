@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
     const bool ragged = kt + 32 > Sk;                                     // wave-uniform: only the last tile masks keys
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float pv = exp2f(fmaf(s[r], c, -lse2));
+      float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
       if (ragged && kt + crow(r, hi) >= Sk) pv = 0.f;
       s[r] = pv * (dp[r] - dl) * p.scale;
     }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
       const bool ok = (qr < Sq) && kok;
       const float L = ok ? lsep[qr] * 1.44269504088896341f : 0.f;
       const float D = ok ? dlp[qr] : 0.f;
-      float pv = ok ? exp2f(fmaf(s[r], c, -L)) : 0.f;
+      float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -L)) : 0.f;
       pr[r] = pv;
       s[r] = pv * (dp[r] - D) * p.scale;
     }
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
       constexpr float DEFER = 6.f;
       if (!__all((mx - m) * c <= DEFER)) {
         const float mn = fmaxf(m, mx);
-        const float alpha = exp2f((m - mn) * c);            // m = -inf on the first block: alpha = 0, O and l are still 0
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);            // m = -inf on the first block: alpha = 0, O and l are still 0
         m = mn;
         l *= alpha;
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(fmaf(s[r], c, -mc));
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
         s[r] = pv;
         rs += pv;
       }
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_wg_kernel(const T2VAttn p) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pv = exp2f(fmaf(s[r], c, -lse2));
+        float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
         if (ragged && kt0 + 32 * kb + crow(r, hi) >= Sk) pv = 0.f;
         s[r] = pv * (dp[r] - dl) * p.scale;
       }
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_wg_kernel(const T2VAttn p) 
       for (int r = 0; r < 16; ++r) {
         const int ql = 32 * qb + crow(r, hi);
         const bool ok = (qt0 + ql < Sq) && kok;
-        const float pv = ok ? exp2f(fmaf(s[r], c, -sL[t & 1][ql])) : 0.f;
+        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -sL[t & 1][ql])) : 0.f;
         pr[r] = pv;
         s[r] = pv * (dp[r] - sDl[t & 1][ql]) * p.scale;
       }
