@@ -359,14 +359,16 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-  PairRegs nx;
-  pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, 0, Sk, tid);
-  pair_store(st[0], nx, tid);
-  __syncthreads();
+  // Tiles are fetched TWO iterations ahead into alternating register sets (a K|V tile's loads have a whole iteration of math
+  // plus a barrier to land before they are written to LDS) — the math of one 64-key tile is shorter than a load round trip.
   const int ntile = (Sk + WG_ROWS - 1) / WG_ROWS;
-  for (int t = 0; t < ntile; ++t) {
+  PairRegs nxa, nxb;
+  pair_fetch(nxa, K, p.k.sstride, V, p.v.sstride, 0, Sk, tid);
+  if (ntile > 1) pair_fetch(nxb, K, p.k.sstride, V, p.v.sstride, WG_ROWS, Sk, tid);
+  pair_store(st[0], nxa, tid);
+  __syncthreads();
+  auto tile_math = [&](int t) {
     const StagePair& cur = st[t & 1];
-    if (t + 1 < ntile) pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, (t + 1) * WG_ROWS, Sk, tid);
     const int kt0 = t * WG_ROWS;
     const bool ragged = kt0 + WG_ROWS > Sk;                 // workgroup-uniform: only the last tile masks keys
 #pragma unroll
@@ -421,7 +423,18 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sv, 1, kk, lane), pb, o1, 0, 0, 0);
       }
     }
-    if (t + 1 < ntile) pair_store(st[(t + 1) & 1], nx, tid);
+  };
+  for (int t = 0; t < ntile; t += 2) {
+    // even tile t: nxb holds tile t+1 (in flight or landed); fetch t+2 into nxa
+    if (t + 2 < ntile) pair_fetch(nxa, K, p.k.sstride, V, p.v.sstride, (t + 2) * WG_ROWS, Sk, tid);
+    tile_math(t);
+    if (t + 1 < ntile) pair_store(st[1], nxb, tid);
+    __syncthreads();
+    if (t + 1 >= ntile) break;
+    // odd tile t+1: nxa holds tile t+2; fetch t+3 into nxb
+    if (t + 3 < ntile) pair_fetch(nxb, K, p.k.sstride, V, p.v.sstride, (t + 3) * WG_ROWS, Sk, tid);
+    tile_math(t + 1);
+    if (t + 2 < ntile) pair_store(st[0], nxa, tid);
     __syncthreads();
   }
   if (qok) {
