@@ -1,0 +1,13 @@
+"""Run ONE attention forward problem a few times (driver for counter passes).  python scripts/attn_shape_run.py nb heads Sq Sk [iters]"""
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, t2v_amd
+import t2v_amd.functional as F
+nb, heads, Sq, Sk = (int(a) for a in sys.argv[1:5])
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+C = heads * 64; bf = torch.bfloat16
+q = torch.randn(nb * Sq, C, device='cuda').to(bf); k = torch.randn(nb * Sk, C, device='cuda').to(bf); v = torch.randn(nb * Sk, C, device='cuda').to(bf)
+ql, kl = F.SeqLayout(nb, Sq, Sq, 0, 1), F.SeqLayout(nb, Sk, Sk, 0, 1)
+with torch.no_grad():
+    for _ in range(iters): F.attention(q, k, v, heads, ql, kl)
+torch.cuda.synchronize()
+print("done")

@@ -14,6 +14,8 @@
 // (sequence stride = H*W*C), per-frame spatial attention and text cross-attention without any permute copy.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -340,8 +342,30 @@ __device__ __forceinline__ void lds_row_frags(bf16x8 (&f)[4], const bf16_t* s, i
   for (int kd = 0; kd < 4; ++kd) f[kd] = *(const bf16x8*)(row + 16 * kd);
 }
 
+// --- fragment reads with the per-lane part of the address computed ONCE (kernel entry) and everything else a compile-time
+// element offset that folds into the ds_read immediate: the counters of the first workgroup forward showed ~20 VALU per MFMA,
+// a third of it LDS address arithmetic re-derived per read
+__device__ __forceinline__ int lane_row_off(int lane) { return (lane & 31) * LDT + 8 * (lane >> 5); }
+__device__ __forceinline__ int lane_tr_off(int lane) {
+  const int gq = lane >> 4, li = lane & 15;
+  return (4 * (gq >> 1) + (li >> 2)) * LDT + 16 * (gq & 1) + 4 * (li & 3);
+}
+template <int OFF>
+__device__ __forceinline__ void lds_row_frags_c(bf16x8 (&f)[4], const bf16_t* lane_base) {
+#pragma unroll
+  for (int kd = 0; kd < 4; ++kd) f[kd] = *(const bf16x8*)(lane_base + OFF + 16 * kd);
+}
+template <int OFF>   // OFF: tile origin (+ 32*fm columns + 16*kk rows) in elements
+__device__ __forceinline__ bf16x8 trfrag_c(const bf16_t* lane_base) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(lane_base + OFF));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(lane_base + OFF + 8 * LDT));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
   __shared__ StagePair st[2];
+  const bf16_t* const lds0 = (const bf16_t*)&st[0];
+  constexpr int STG = sizeof(StagePair) / 2, VOFF = WG_ROWS * LDT;     // element offsets: next stage, V inside a stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y, b = blockIdx.z;
   const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
@@ -367,15 +391,16 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
   if (ntile > 1) pair_fetch(nxb, K, p.k.sstride, V, p.v.sstride, WG_ROWS, Sk, tid);
   pair_store(st[0], nxa, tid);
   __syncthreads();
-  auto tile_math = [&](int t) {
-    const StagePair& cur = st[t & 1];
+  const bf16_t* const rowb = lds0 + lane_row_off(lane);
+  const bf16_t* const trb = lds0 + lane_tr_off(lane);
+  auto tile_math = [&](auto stage_c, int t) {
+    constexpr int S0 = decltype(stage_c)::value * STG;
     const int kt0 = t * WG_ROWS;
     const bool ragged = kt0 + WG_ROWS > Sk;                 // workgroup-uniform: only the last tile masks keys
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      if (kt0 + 32 * kb >= Sk) break;
+    auto block = [&](auto kb_c) {
+      constexpr int kb = decltype(kb_c)::value;
       bf16x8 kf[4];
-      lds_row_frags(kf, cur.a, kb, lane);
+      lds_row_frags_c<S0 + 32 * kb * LDT>(kf, rowb);
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -415,25 +440,31 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
       }
       rs += __shfl_xor(rs, 32);
       l += rs;
-      const bf16_t* sv = cur.b + 32 * kb * LDT;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 pb = pack8(s, kk);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sv, 0, kk, lane), pb, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sv, 1, kk, lane), pb, o1, 0, 0, 0);
+      constexpr int V0 = S0 + VOFF + 32 * kb * LDT;
+      {
+        const bf16x8 pb = pack8(s, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_c<V0>(trb), pb, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_c<V0 + 32>(trb), pb, o1, 0, 0, 0);
       }
-    }
+      {
+        const bf16x8 pb = pack8(s, 1);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_c<V0 + 16 * LDT>(trb), pb, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_c<V0 + 16 * LDT + 32>(trb), pb, o1, 0, 0, 0);
+      }
+    };
+    block(std::integral_constant<int, 0>{});
+    if (kt0 + 32 < Sk) block(std::integral_constant<int, 1>{});
   };
   for (int t = 0; t < ntile; t += 2) {
     // even tile t: nxb holds tile t+1 (in flight or landed); fetch t+2 into nxa
     if (t + 2 < ntile) pair_fetch(nxa, K, p.k.sstride, V, p.v.sstride, (t + 2) * WG_ROWS, Sk, tid);
-    tile_math(t);
+    tile_math(std::integral_constant<int, 0>{}, t);
     if (t + 1 < ntile) pair_store(st[1], nxb, tid);
     __syncthreads();
     if (t + 1 >= ntile) break;
     // odd tile t+1: nxa holds tile t+2; fetch t+3 into nxb
     if (t + 3 < ntile) pair_fetch(nxb, K, p.k.sstride, V, p.v.sstride, (t + 3) * WG_ROWS, Sk, tid);
-    tile_math(t + 1);
+    tile_math(std::integral_constant<int, 1>{}, t + 1);
     if (t + 2 < ntile) pair_store(st[0], nxa, tid);
     __syncthreads();
   }
