@@ -160,6 +160,7 @@ def gemm_roofline(trainer, batch):
         records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False, 0.0))
 
     conv3d, attn, wgrad, shapes, norms = [], [], [], [], []
+    wgrad_layers = [0]
     nv = F.nv
     orig_call = nv.call
 
@@ -167,7 +168,7 @@ def gemm_roofline(trainer, batch):
             "t2v_gn_bwd_apply": (6, "gn_bwd"), "t2v_layernorm_fwd": (None, "ln_fwd"), "t2v_layernorm_bwd": (None, "ln_bwd")}
 
     def timed_call(name, *a):
-        if name not in ("t2v_attn_fwd", "t2v_attn_bwd", "t2v_lora_wgrad") and name not in NORM:
+        if name not in ("t2v_attn_fwd", "t2v_attn_bwd", "t2v_lora_wgrad", "t2v_lora_wgrad_batch") and name not in NORM:
             return orig_call(name, *a)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -188,8 +189,19 @@ def gemm_roofline(trainer, batch):
                 alg = {"t2v_gn_stats": 0, "t2v_gn_apply": 2, "t2v_gn_bwd_stats": 0, "t2v_gn_bwd_apply": 3 + (1 if addend else 0)}[name] * E * 2
             norms.append((kind, alg, moved, s, e))
             return r
+        if name == "t2v_lora_wgrad_batch":      # a[0] = array of descriptors, a[1] = their number: one launch for all of them
+            fl = by = 0.0
+            for i in range(a[1]):
+                d = a[0][i]
+                taps = d.geom.KH * d.geom.KW if d.conv else 1
+                fl += 2.0 * d.rp * (d.N + taps * d.C) * d.rows
+                by += (d.N + d.C) * d.rows * 2.0
+            wgrad.append((fl, by, s, e))
+            wgrad_layers[0] += a[1]
+            return r
         d = a[0]._obj
         if name == "t2v_lora_wgrad":      # each activation operand read once; fp32 factor gradients accumulated
+            wgrad_layers[0] += 1
             taps = d.geom.KH * d.geom.KW if d.conv else 1
             wgrad.append((2.0 * d.rp * (d.N + taps * d.C) * d.rows, (d.N + d.C) * d.rows * 2.0, s, e))
             return r
@@ -234,6 +246,7 @@ def gemm_roofline(trainer, batch):
     if wgrad:
         ns["lora_factor_gradients"] = both_roofs(sum(c[0] for c in wgrad), sum(c[1] for c in wgrad),
                                                  sum(c[2].elapsed_time(c[3]) for c in wgrad), len(wgrad))
+        ns["lora_factor_gradients"]["layers"] = wgrad_layers[0]
     for kind in ("temporal", "spatial", "text_cross"):
         rs = [r for r in attn if r[0] == kind]
         if rs:

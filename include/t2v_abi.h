@@ -227,6 +227,15 @@ typedef struct T2VLoraWgrad {
   float alpha;
 } T2VLoraWgrad;
 int t2v_lora_wgrad(const T2VLoraWgrad* p, t2v_stream_t stream);
+/* The same for MANY layers in one launch (the train step queues the descriptors of a backward pass and flushes them in a few
+ * batches: 568 launches of ~15 us become streaming work without per-layer ramps and tails).  `host_staging` = pinned host
+ * memory and `device_table` = device memory, each of t2v_lora_wgrad_batch_bytes(nlayers) bytes, owned by the caller and left
+ * untouched until the launch has run (inside a stream capture the staging copy is a graph node that re-reads the staging
+ * buffer at every replay: keep one staging/table pair per captured batch).  Every operand of every descriptor must stay
+ * alive until the launch has run. */
+long long t2v_lora_wgrad_batch_bytes(int nlayers);
+int t2v_lora_wgrad_batch(const T2VLoraWgrad* descs, int nlayers, void* host_staging, void* device_table, long long table_bytes,
+                         t2v_stream_t stream);
 
 /* ---- LoRA merge: effective weights of all wrapped layers of a model in ONE streaming launch.
  *   W_eff[n, tap, c] = W[n, tap, c] + scale * sum_j U[j, n] * D[j, tap, c]

@@ -304,6 +304,48 @@ def test_lora_wgrad(nimg, H, W, KH, KW, C, N, rp):
     assert eu < 1e-3 and ed < 1e-3        # fp32 accumulation of exact bf16 products: only summation order differs
 
 
+def test_lora_wgrad_batch_equals_per_layer_launches():
+    """t2v_lora_wgrad_batch: the descriptors of several layers (linear, 3x3, (3,1,1); one or two rank passes; different row
+    counts) in ONE launch give what the per-layer launches give (fp32 atomics: summation order only)."""
+    import ctypes as C_
+    import t2v_amd.native as nv
+    g = torch.Generator().manual_seed(2024)
+    layers = [(1, 1, 1000, 1, 1, 64, 128, 16), (3, 8, 8, 3, 3, 64, 128, 16), (2, 4, 48, 3, 1, 128, 128, 16), (1, 1, 4096, 1, 1, 320, 320, 16),
+              (2, 5, 7, 3, 3, 24, 40, 32), (1, 1, 77, 1, 1, 1024, 320, 16), (1, 16, 16, 3, 3, 8, 320, 24)]
+    descs, outs, keep = [], [], []
+    for nimg, H, W, KH, KW, C, N, rp in layers:
+        conv = KH * KW > 1
+        rows = nimg * H * W if conv else W
+        taps = KH * KW
+        t = _bf(torch.randn(rows, rp, generator=g)).cuda(); dy = _bf(torch.randn(rows, N, generator=g)).cuda()
+        dt = _bf(torch.randn(rows, rp, generator=g)).cuda(); x = _bf(torch.randn(rows, C, generator=g)).cuda()
+        pair = []
+        for _ in range(2):                   # [0]: per-layer launches, [1]: the batch
+            dU = torch.zeros(rp, N, device="cuda"); dD = torch.zeros(rp, taps * C, device="cuda")
+            w = nv.LoraWgrad()
+            w.rows, w.rp, w.conv = rows, rp, int(conv)
+            w.t, w.ldt, w.dy, w.lddy, w.N = t.data_ptr(), rp, dy.data_ptr(), N, N
+            w.dU, w.lddu = dU.data_ptr(), N
+            w.dt, w.lddt, w.x, w.ldx, w.C = dt.data_ptr(), rp, x.data_ptr(), C, C
+            w.dD, w.lddd = dD.data_ptr(), taps * C
+            if conv:
+                w.geom = nv.ConvGeom(C, H, W, H, W, KH, KW, 1, 1, KH // 2, KW // 2, 1, 0)
+            w.alpha = 0.7
+            pair.append((w, dU, dD))
+        keep.append((t, dy, dt, x))
+        nv.call("t2v_lora_wgrad", C_.byref(pair[0][0]), nv.stream())
+        descs.append(pair[1][0]); outs.append((pair[0][1], pair[0][2], pair[1][1], pair[1][2]))
+    n = len(descs)
+    arr = (nv.LoraWgrad * n)(*descs)
+    nbytes = int(nv.lib().t2v_lora_wgrad_batch_bytes(n))
+    host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True); dev = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    nv.call("t2v_lora_wgrad_batch", arr, n, host.data_ptr(), dev.data_ptr(), nbytes, nv.stream())
+    torch.cuda.synchronize()
+    for dU1, dD1, dU2, dD2 in outs:
+        assert float(dU1.abs().sum()) > 0 and float(dD1.abs().sum()) > 0
+        assert relerr(dU2, dU1) < 1e-5 and relerr(dD2, dD1) < 1e-5
+
+
 def test_norm_passthrough_residual_gradient():
     """group_norm_res / layer_norm_res: the second output is x for its residual use; dx = norm_bwd(dy) + d(residual)
     is formed inside the backward kernel (t2v_gn_bwd_apply / t2v_layernorm_bwd `addend`)."""

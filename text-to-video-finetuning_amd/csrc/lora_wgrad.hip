@@ -158,11 +158,37 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(Args a) {
     wgrad_body<TAPS_D>(a.d, r_begin, r_end, (tile - a.u.tiles) * 64, a.g, a.rk, a.alpha, smem);
 }
 
-}  // namespace
+// Many layers in ONE launch (t2v_lora_wgrad_batch): a device table of per-pass arguments + the first workgroup of every
+// pass; a workgroup finds its pass by binary search and runs the same body.  The per-layer launches of a C2 step are
+// 568 kernels of ~15 us whose ramp and tail dominate (most layers move < 10 MB); batched they stream back to back.
+__global__ __launch_bounds__(256) void lora_wgrad_batch_kernel(const Args* __restrict__ jobs, const int* __restrict__ first, int njobs) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KR * PITCH + 9 * KR * SP];
+  int lo = 0, hi = njobs - 1;
+  const int b = (int)blockIdx.x;
+  while (lo < hi) {                          // largest j with first[j] <= b (wave-uniform: scalar loads)
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const Args a = jobs[lo];
+  const int rel = b - first[lo];
+  const int ntiles = a.u.tiles + a.d.tiles;
+  const int tile = rel % ntiles, chunk = rel / ntiles;
+  const long long r_begin = (long long)chunk * a.chunk_rows;
+  const long long r_end = std::min(a.rows, r_begin + a.chunk_rows);
+  if (r_begin >= r_end) return;
+  if (tile < a.u.tiles) {
+    wgrad_body<1>(a.u, r_begin, r_end, tile * 64, a.g, a.rk, a.alpha, smem);
+    return;
+  }
+  const int c0 = (tile - a.u.tiles) * 64, taps = a.g.KH * a.g.KW;
+  if (taps == 1) wgrad_body<1>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+  else if (taps == 3) wgrad_body<3>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+  else wgrad_body<9>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+}
 
-extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
-  T2V_CHECK_ARG(pp, "t2v_lora_wgrad: null descriptor");
-  const T2VLoraWgrad& p = *pp;
+// argument checks + the passes (one per 16 rank rows) of one layer; returns the number of passes appended or a negative code
+int wgrad_passes(const T2VLoraWgrad& p, Args* out, int* blocks) {
   T2V_CHECK_ARG(p.rows > 0 && p.rows < (1LL << 31) && p.t && p.dy && p.dU && p.dt && p.x && p.dD, "t2v_lora_wgrad: bad args");
   T2V_CHECK_ARG(p.rp >= 8 && p.rp <= 32 && p.rp % 8 == 0, "t2v_lora_wgrad: padded rank must be 8, 16, 24 or 32 (got %d)", p.rp);
   T2V_CHECK_ARG(p.N > 0 && p.N % 8 == 0 && p.C > 0 && p.C % 8 == 0 && p.ldt % 8 == 0 && p.lddt % 8 == 0 && p.lddy % 8 == 0 &&
@@ -181,8 +207,9 @@ extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
     g.Hv = g.Wv = g.Ho = g.Wo = g.KH = g.KW = 1;
   }
   T2V_CHECK_ARG(p.lddu >= p.N && p.lddd >= (long long)taps * p.C, "t2v_lora_wgrad: output leading dimensions too small");
-  for (int r0 = 0; r0 < p.rp; r0 += 16) {     // one pass per 16 rank rows
-    Args a;
+  int n = 0;
+  for (int r0 = 0; r0 < p.rp; r0 += 16, ++n) {     // one pass per 16 rank rows
+    Args& a = out[n];
     a.rk = std::min(16, p.rp - r0);
     a.u = Prob{(const bf16_t*)p.dy, p.lddy, p.N, (const bf16_t*)p.t + r0, p.ldt, p.dU + (long long)r0 * p.lddu, p.lddu, (p.N + 63) / 64};
     a.d = Prob{(const bf16_t*)p.x, p.ldx, p.C, (const bf16_t*)p.dt + r0, p.lddt, p.dD + (long long)r0 * p.lddd, p.lddd, (p.C + 63) / 64};
@@ -195,7 +222,59 @@ extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
     long long nchunks = std::max<long long>(1, std::min<long long>(nsteps, (384 + ntiles - 1) / ntiles));
     a.chunk_rows = (int)(((nsteps + nchunks - 1) / nchunks) * KR);
     nchunks = (p.rows + a.chunk_rows - 1) / a.chunk_rows;
-    dim3 grid((unsigned)(nchunks * ntiles));
+    blocks[n] = (int)(nchunks * ntiles);
+  }
+  return n;
+}
+
+}  // namespace
+
+extern "C" long long t2v_lora_wgrad_batch_bytes(int nlayers) { return (long long)nlayers * 2 * (long long)(sizeof(Args) + sizeof(int)) + 64; }
+
+extern "C" int t2v_lora_wgrad_batch(const T2VLoraWgrad* descs, int nlayers, void* host_staging, void* device_table,
+                                    long long table_bytes, t2v_stream_t stream) {
+  T2V_CHECK_ARG(descs && nlayers > 0 && host_staging && device_table, "t2v_lora_wgrad_batch: bad args");
+  T2V_CHECK_ARG(table_bytes >= t2v_lora_wgrad_batch_bytes(nlayers), "t2v_lora_wgrad_batch: table buffers too small (%lld bytes for %d layers)",
+                table_bytes, nlayers);
+  // staging layout: [2*nlayers] Args, then [2*nlayers] first-workgroup indices (host builds it, ONE async copy brings it over;
+  // inside a stream capture the copy becomes a graph node that re-reads the same pinned staging buffer at every replay)
+  Args* jobs = (Args*)host_staging;
+  int* first = (int*)((unsigned char*)host_staging + (size_t)nlayers * 2 * sizeof(Args));
+  int njobs = 0;
+  long long total = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    int blocks[2];
+    const int n = wgrad_passes(descs[l], jobs + njobs, blocks);
+    if (n < 0) return n;
+    for (int q = 0; q < n; ++q) {
+      first[njobs + q] = (int)total;
+      total += blocks[q];
+    }
+    njobs += n;
+  }
+  T2V_CHECK_ARG(total < (1LL << 31), "t2v_lora_wgrad_batch: too many workgroups");
+  const size_t args_bytes = (size_t)nlayers * 2 * sizeof(Args);
+  if (hipMemcpyAsync(device_table, host_staging, args_bytes + (size_t)njobs * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream) !=
+      hipSuccess) {
+    t2v_set_error("t2v_lora_wgrad_batch: staging copy failed: %s", hipGetErrorString(hipGetLastError()));
+    return T2V_ELAUNCH;
+  }
+  hipLaunchKernelGGL(lora_wgrad_batch_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const Args*)device_table,
+                     (const int*)((const unsigned char*)device_table + args_bytes), njobs);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
+  T2V_CHECK_ARG(pp, "t2v_lora_wgrad: null descriptor");
+  Args pass[2];
+  int blocks[2];
+  const int n = wgrad_passes(*pp, pass, blocks);
+  if (n < 0) return n;
+  for (int q = 0; q < n; ++q) {
+    const Args& a = pass[q];
+    const int taps = a.g.KH * a.g.KW;
+    dim3 grid((unsigned)blocks[q]);
     if (taps == 1)
       hipLaunchKernelGGL(lora_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (taps == 3)

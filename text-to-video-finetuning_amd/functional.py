@@ -326,9 +326,76 @@ def _side_stream():
 
 def join_side_stream():
     """Make the current stream wait for every factor-gradient launch issued so far; release their operand references."""
+    flush_wgrads()
     if _side["stream"] is not None and _side["refs"]:
         torch.cuda.current_stream().wait_stream(_side["stream"])
     _side["refs"].clear()
+
+
+# ---- factor-gradient batching: the t2v_lora_wgrad descriptors of a backward pass are queued and run as a few
+# t2v_lora_wgrad_batch launches (every T2V_WGRAD_BATCH_LAYERS layers and at the end of the backward) instead of one ~15 us
+# kernel per layer.  T2V_WGRAD_BATCH=0 restores the per-layer launches.
+_wq = {"enabled": os.environ.get("T2V_WGRAD_BATCH", "1") != "0", "descs": [], "pool": [], "next": 0, "captured": [], "reserve": [],
+       "flush_at": int(os.environ.get("T2V_WGRAD_BATCH_LAYERS", "96"))}
+
+
+def _wgrad_launch(w, keep):
+    """Run (or queue) the factor gradients of one layer; `keep` = every tensor the descriptor points into."""
+    if not _wq["enabled"]:
+        nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+        return
+    _wq["descs"].append(w)
+    _side["refs"].append(keep)               # operands stay alive until join_side_stream()
+    if len(_wq["descs"]) >= _wq["flush_at"]:
+        flush_wgrads()
+    else:
+        _join_at_end_of_backward()           # (outside a backward pass this flushes and joins at once)
+
+
+_WQ_BYTES = 1 << 16       # one staging / table buffer (a batch of T2V_WGRAD_BATCH_LAYERS layers needs ~45 KB)
+
+
+def _wgrad_staging(nbytes, device):
+    """(pinned host staging, device table, event) for one batch.  Eager: a ring of reusable pairs, each guarded by the event of
+    its last copy.  Inside a stream capture: a pair from a reserve that eager launches keep stocked (pinned memory cannot be
+    allocated while a capture is open) and that is never reused — the graph re-reads the staging buffer at every replay."""
+    if nbytes > _WQ_BYTES:
+        raise RuntimeError(f"t2v_amd: factor-gradient batch of {nbytes} bytes exceeds the staging buffers (lower T2V_WGRAD_BATCH_LAYERS)")
+    if torch.cuda.is_current_stream_capturing():
+        if not _wq["reserve"]:
+            raise RuntimeError("t2v_amd: no pinned staging buffer left for a captured factor-gradient batch; run one eager "
+                               "train step before capturing (DenoiseTrainer.capture does)")
+        host = _wq["reserve"].pop()
+        pair = (host, torch.empty(_WQ_BYTES, dtype=torch.uint8, device=device), None)
+        _wq["captured"].append(pair)
+        return pair
+    while len(_wq["reserve"]) < 32:          # stock for later captures
+        _wq["reserve"].append(torch.empty(_WQ_BYTES, dtype=torch.uint8, pin_memory=True))
+    pool = _wq["pool"]
+    if len(pool) < 16:
+        pool.append([torch.empty(_WQ_BYTES, dtype=torch.uint8, pin_memory=True),
+                     torch.empty(_WQ_BYTES, dtype=torch.uint8, device=device), torch.cuda.Event()])
+        return pool[-1]
+    slot = pool[_wq["next"] % len(pool)]
+    _wq["next"] += 1
+    slot[2].synchronize()                    # its previous copy has been consumed (it is from an earlier step: no wait in practice)
+    if slot[1].device != device:
+        slot[1] = torch.empty(_WQ_BYTES, dtype=torch.uint8, device=device)
+    return slot
+
+
+def flush_wgrads():
+    descs = _wq["descs"]
+    n = len(descs)
+    if not n:
+        return
+    arr = (nv.LoraWgrad * n)(*descs)
+    descs.clear()
+    nbytes = int(nv.lib().t2v_lora_wgrad_batch_bytes(n))
+    host, dev, ev = _wgrad_staging(nbytes, torch.device("cuda", torch.cuda.current_device()))
+    nv.call("t2v_lora_wgrad_batch", arr, n, host.data_ptr(), dev.data_ptr(), nbytes, nv.stream())
+    if ev is not None:
+        ev.record()
 
 
 def _end_of_backward():
@@ -351,6 +418,10 @@ def _fork_side(work, keep):
     with torch.cuda.stream(side):
         work()
     _side["refs"].append(keep)               # keep operands alive until join_side_stream()
+    _join_at_end_of_backward()
+
+
+def _join_at_end_of_backward():
     if not _side["cb"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
@@ -514,7 +585,7 @@ def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=Non
             if conv:
                 w.geom = g
             w.alpha = scale
-            nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+            _wgrad_launch(w, (tt, dtt, x, keep))
         else:                     # strided / resampled windows: two K-major GEMMs in one launch
             launch_gemm_pair(
                 dict(M=e.rp, N=npad, K=M, A=tt.data_ptr(), lda=_ld(tt), a_trans=1, B=dy_ptr, ldb=lddy, b_trans=1,
@@ -674,7 +745,7 @@ class _LoraGroupMerged(torch.autograd.Function):
                 w.x, w.ldx, w.C = x.data_ptr(), _ld(x), cin_p
                 w.dD, w.lddd = g.down_g.data_ptr() + i * rpe * cin_p * 4, cin_p
                 w.alpha = scale
-                nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+                _wgrad_launch(w, (t, dt, x, keep))
 
         if _side["enabled"]:
             _fork_side(work, keep)
@@ -783,7 +854,7 @@ class _LoraGroup(torch.autograd.Function):
                 w.x, w.ldx, w.C = x.data_ptr(), _ld(x), cin_p
                 w.dD, w.lddd = g.down_g.data_ptr() + i * rpe * cin_p * 4, cin_p
                 w.alpha = scale
-                nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
+                _wgrad_launch(w, (t, dt, x, keep))
 
         if _side["enabled"]:
             _fork_side(wgrads, (keep, t, dt, x))

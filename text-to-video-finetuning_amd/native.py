@@ -117,6 +117,8 @@ SYMBOLS = {
     "t2v_lowrank_update_drop": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_float, c_ull,
                                  c_void_p], c_int),
     "t2v_lora_wgrad": ([C.POINTER(LoraWgrad), c_void_p], c_int),
+    "t2v_lora_wgrad_batch_bytes": ([c_int], c_ll),
+    "t2v_lora_wgrad_batch": ([C.POINTER(LoraWgrad), c_int, c_void_p, c_void_p, c_ll, c_void_p], c_int),
     "t2v_lowrank_window_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, C.POINTER(ConvGeom), c_ll, c_int, c_int,
                                    c_float, c_void_p], c_int),
     "t2v_lora_merge_plan": ([C.POINTER(LoraMergeJob), c_int, c_void_p, c_ll], c_ll),
