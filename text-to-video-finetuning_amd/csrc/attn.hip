@@ -54,11 +54,11 @@ __device__ __forceinline__ bf16x8 trfrag(const bf16_t* s, int fm, int kk, int la
   bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(s + (k0 + 8) * LDT + col));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int kk) {
-  bf16x8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[8 * kk + j]);
-  return o;
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int kk) {      // four v_cvt_pk_bf16_f32, no per-element assembly
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 q = {pack2bf(v[8 * kk], v[8 * kk + 1]), pack2bf(v[8 * kk + 2], v[8 * kk + 3]), pack2bf(v[8 * kk + 4], v[8 * kk + 5]),
+                   pack2bf(v[8 * kk + 6], v[8 * kk + 7])};
+  return __builtin_bit_cast(bf16x8, q);
 }
 // store the lane's 32 values of a transposed accumulator pair (lane = row `row`, regs = features) as bf16
 __device__ __forceinline__ void store_rowT(bf16_t* base, long long ss, int row, const f32x16& a0, const f32x16& a1, float mul,
@@ -651,6 +651,244 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_wg_kernel(const T2VAttn p) 
   }
 }
 
+// ---- backward with TWO 32-row blocks per wave (workgroup = 256 queries / keys).  The one-block workgroup kernels above lose to
+// the one-wave kernels: every 32x32 score block needs the staged tile in two orientations (row fragments for the score
+// products, transposed fragments for the gradient products) — 16 KB of LDS reads per 12-16 MFMAs per wave — and one block per
+// wave is a single dependent chain (scores -> exp -> gradient products) with nothing to overlap at one wave per SIMD.  Here
+// every fragment read from LDS feeds two blocks (half the LDS traffic per MFMA, half the global traffic again), and the two
+// blocks' chains are independent, so one block's MFMAs run under the other's exponentials.
+template <int V>
+using ic = std::integral_constant<int, V>;
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_wg2_kernel(const T2VAttn p) {
+  __shared__ StagePair st[2];
+  constexpr int VOFF = WG_ROWS * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  const bf16_t* O = (const bf16_t*)p.o.ptr + op_off(p.o, b, h);
+  const bf16_t* dO = (const bf16_t*)p.d_o.ptr + op_off(p.d_o, b, h);
+  bf16_t* dQ = (bf16_t*)p.dq.ptr + op_off(p.dq, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const float c = p.scale * 1.44269504088896341f;
+  int q[2];
+  bool qok[2];
+  bf16x8 qf[2][4], dof[2][4];
+  float dl[2], lse2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    q[j] = blockIdx.x * 256 + wave * 64 + 32 * j + l31;
+    qok[j] = q[j] < Sq;
+    float d = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      qf[j][kd] = ldg8(Q + (long long)q[j] * p.q.sstride + 16 * kd + 8 * hi, qok[j]);
+      dof[j][kd] = ldg8(dO + (long long)q[j] * p.d_o.sstride + 16 * kd + 8 * hi, qok[j]);
+      const bf16x8 of = ldg8(O + (long long)q[j] * p.o.sstride + 16 * kd + 8 * hi, qok[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += bf2f((unsigned short)of[e]) * bf2f((unsigned short)dof[j][kd][e]);
+    }
+    d += __shfl_xor(d, 32);
+    dl[j] = d;
+    const long long sidx = ((long long)b * p.heads + h) * Sq + q[j];
+    if (qok[j] && hi == 0) p.delta[sidx] = d;
+    lse2[j] = qok[j] ? p.lse[sidx] * 1.44269504088896341f : 0.f;      // p = exp2(s*c - lse*log2e)
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][0][r] = acc[j][1][r] = 0.f;
+  const int roff = lane_row_off(lane), toff = lane_tr_off(lane);
+  PairRegs nx;
+  pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, 0, Sk, tid);
+  pair_store(st[0], nx, tid);
+  __syncthreads();
+  const int ntile = (Sk + WG_ROWS - 1) / WG_ROWS;
+  for (int t = 0; t < ntile; ++t) {
+    const bf16_t* cur = st[t & 1].a;
+    const bf16_t* rb = cur + roff;
+    const bf16_t* tb = cur + toff;
+    if (t + 1 < ntile) pair_fetch(nx, K, p.k.sstride, V, p.v.sstride, (t + 1) * WG_ROWS, Sk, tid);
+    const int kt0 = t * WG_ROWS;
+    const bool ragged = kt0 + WG_ROWS > Sk;
+    auto block = [&](auto KB) {
+      constexpr int kb = decltype(KB)::value, K0 = 32 * kb * LDT;
+      bf16x8 kf[4], vf[4], tk[2][2];
+      lds_row_frags_c<K0>(kf, rb);
+      lds_row_frags_c<VOFF + K0>(vf, rb);
+      tk[0][0] = trfrag_c<K0>(tb);
+      tk[0][1] = trfrag_c<K0 + 32>(tb);
+      tk[1][0] = trfrag_c<K0 + 16 * LDT>(tb);
+      tk[1][1] = trfrag_c<K0 + 16 * LDT + 32>(tb);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 4; ++kd) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kd], qf[j][kd], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kd], dof[j][kd], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2[j]));
+          if (ragged && kt0 + 32 * kb + crow(r, hi) >= Sk) pv = 0.f;
+          s[r] = pv * (dp[r] - dl[j]) * p.scale;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 db = pack8(s, kk);
+          acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[kk][0], db, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[kk][1], db, acc[j][1], 0, 0, 0);
+        }
+      }
+    };
+    block(ic<0>{});
+    if (kt0 + 32 < Sk) block(ic<1>{});
+    if (t + 1 < ntile) pair_store(st[(t + 1) & 1], nx, tid);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (qok[j]) store_rowT(dQ, p.dq.sstride, q[j], acc[j][0], acc[j][1], 1.f, hi);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_wg2_kernel(const T2VAttn p) {
+  __shared__ StagePair st[2];
+  __shared__ __attribute__((aligned(16))) float sL[2][WG_ROWS], sDl[2][WG_ROWS];
+  constexpr int VOFF = WG_ROWS * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Q = (const bf16_t*)p.q.ptr + op_off(p.q, b, h);
+  const bf16_t* K = (const bf16_t*)p.k.ptr + op_off(p.k, b, h);
+  const bf16_t* V = (const bf16_t*)p.v.ptr + op_off(p.v, b, h);
+  const bf16_t* dO = (const bf16_t*)p.d_o.ptr + op_off(p.d_o, b, h);
+  bf16_t* dK = (bf16_t*)p.dk.ptr + op_off(p.dk, b, h);
+  bf16_t* dV = (bf16_t*)p.dv.ptr + op_off(p.dv, b, h);
+  const int Sq = p.Sq, Sk = p.Sk;
+  int key[2];
+  bool kok[2];
+  bf16x8 kf[2][4], vf[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    key[j] = blockIdx.x * 256 + wave * 64 + 32 * j + l31;
+    kok[j] = key[j] < Sk;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      kf[j][kd] = ldg8(K + (long long)key[j] * p.k.sstride + 16 * kd + 8 * hi, kok[j]);
+      vf[j][kd] = ldg8(V + (long long)key[j] * p.v.sstride + 16 * kd + 8 * hi, kok[j]);
+    }
+  }
+  const float* lsep = p.lse + ((long long)b * p.heads + h) * Sq;
+  const float* dlp = p.delta + ((long long)b * p.heads + h) * Sq;
+  const float c = p.scale * 1.44269504088896341f;
+  f32x16 ka[2][2], va[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ka[j][0][r] = ka[j][1][r] = va[j][0][r] = va[j][1][r] = 0.f;
+  const int roff = lane_row_off(lane), toff = lane_tr_off(lane);
+  PairRegs nx;
+  float nl = 0.f, nd = 0.f;                                 // threads 0..63 carry the tile's lse (base 2) / delta rows
+  auto fetch_rows = [&](int row0) {
+    if (tid < WG_ROWS) {
+      const int qr = row0 + tid;
+      nl = qr < Sq ? lsep[qr] * 1.44269504088896341f : 0.f;
+      nd = qr < Sq ? dlp[qr] : 0.f;
+    }
+  };
+  pair_fetch(nx, Q, p.q.sstride, dO, p.d_o.sstride, 0, Sq, tid);
+  fetch_rows(0);
+  pair_store(st[0], nx, tid);
+  if (tid < WG_ROWS) {
+    sL[0][tid] = nl;
+    sDl[0][tid] = nd;
+  }
+  __syncthreads();
+  const int ntile = (Sq + WG_ROWS - 1) / WG_ROWS;
+  for (int t = 0; t < ntile; ++t) {
+    const bf16_t* cur = st[t & 1].a;
+    const bf16_t* rb = cur + roff;
+    const bf16_t* tb = cur + toff;
+    const float* cl = sL[t & 1];
+    const float* cd = sDl[t & 1];
+    if (t + 1 < ntile) {
+      pair_fetch(nx, Q, p.q.sstride, dO, p.d_o.sstride, (t + 1) * WG_ROWS, Sq, tid);
+      fetch_rows((t + 1) * WG_ROWS);
+    }
+    const int qt0 = t * WG_ROWS;
+    const bool ragged = qt0 + WG_ROWS > Sq;
+    auto block = [&](auto QB) {
+      constexpr int qb = decltype(QB)::value, Q0 = 32 * qb * LDT;
+      bf16x8 qa[4], da[4], tq[2][2], td[2][2];
+      lds_row_frags_c<Q0>(qa, rb);
+      lds_row_frags_c<VOFF + Q0>(da, rb);
+      tq[0][0] = trfrag_c<Q0>(tb);
+      tq[0][1] = trfrag_c<Q0 + 32>(tb);
+      tq[1][0] = trfrag_c<Q0 + 16 * LDT>(tb);
+      tq[1][1] = trfrag_c<Q0 + 16 * LDT + 32>(tb);
+      td[0][0] = trfrag_c<VOFF + Q0>(tb);
+      td[0][1] = trfrag_c<VOFF + Q0 + 32>(tb);
+      td[1][0] = trfrag_c<VOFF + Q0 + 16 * LDT>(tb);
+      td[1][1] = trfrag_c<VOFF + Q0 + 16 * LDT + 32>(tb);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 4; ++kd) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kd], kf[j][kd], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[kd], vf[j][kd], dp, 0, 0, 0);
+        }
+        f32x16 pr;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {                       // rows crow(4*g4 + i, hi) = 8*g4 + 4*hi + i: four consecutive floats
+          const float4 l4 = *(const float4*)(cl + 32 * qb + 8 * g4 + 4 * hi);
+          const float4 d4 = *(const float4*)(cd + 32 * qb + 8 * g4 + 4 * hi);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g4 + i;
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lv[i]));
+            if (!kok[j] || (ragged && qt0 + 32 * qb + crow(r, hi) >= Sq)) pv = 0.f;
+            pr[r] = pv;
+            s[r] = pv * (dp[r] - dv[i]) * p.scale;
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 pb = pack8(pr, kk), db = pack8(s, kk);
+          va[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[kk][0], pb, va[j][0], 0, 0, 0);
+          va[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[kk][1], pb, va[j][1], 0, 0, 0);
+          ka[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[kk][0], db, ka[j][0], 0, 0, 0);
+          ka[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[kk][1], db, ka[j][1], 0, 0, 0);
+        }
+      }
+    };
+    block(ic<0>{});
+    if (qt0 + 32 < Sq) block(ic<1>{});
+    if (t + 1 < ntile) {
+      pair_store(st[(t + 1) & 1], nx, tid);
+      if (tid < WG_ROWS) {
+        sL[(t + 1) & 1][tid] = nl;
+        sDl[(t + 1) & 1][tid] = nd;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (kok[j]) {
+      store_rowT(dK, p.dk.sstride, key[j], ka[j][0], ka[j][1], 1.f, hi);
+      store_rowT(dV, p.dv.sstride, key[j], va[j][0], va[j][1], 1.f, hi);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Short self-attention sequences (S = Sq = Sk <= 16, S | 32: the temporal attention over F frames): P = 32/S sequences
 // of consecutive batches are packed into ONE 32-row tile — lane&31 = packed row = (sequence lane/S, position lane%S) —
@@ -832,13 +1070,19 @@ bool use_wg(int rows) {
   return !off && rows >= 128;
 }
 
-// The backward workgroup kernels read BOTH MFMA operands of the streamed tile from LDS (row-major fragments + transposed
-// fragments: 2x the LDS instructions of the one-wave kernels, which take the row-major fragments straight from memory) and
-// measured 15-20 % slower at S = 2880 / 9216 (scripts/attn_bench.py): LDS-read-bound.  They stay selectable
-// (T2V_ATTN_WG_BWD=1) and tested; the default backward is the one-wave pair.
+// One-block-per-wave workgroup backward (128 rows per workgroup): reads BOTH MFMA operands of the streamed tile from LDS and
+// measured 15-20 % slower than the one-wave kernels at S = 2880 / 9216 (LDS-read-bound, one dependent chain per wave).
+// Selectable for the A/B with T2V_ATTN_WG_BWD=1; superseded by the two-block kernels below.
 bool use_wg_bwd(int rows) {
   static const int on = [] { const char* e = getenv("T2V_ATTN_WG_BWD"); return e && e[0] == '1'; }();
   return on && rows >= 128;
+}
+
+// two 32-row blocks per wave (256 rows per workgroup): T2V_ATTN_WG_BWD=2 (the default) selects them for runs of >= 256 rows,
+// T2V_ATTN_WG_BWD=0 keeps the one-wave pair everywhere
+bool use_wg2_bwd(int rows) {
+  static const int mode = [] { const char* e = getenv("T2V_ATTN_WG_BWD"); return e ? atoi(e) : 2; }();
+  return mode == 2 && rows >= 256;
 }
 
 int check_op(const char* fn, const char* name, const T2VAttnOperand& o) {
@@ -893,13 +1137,17 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
   }
   T2V_CHECK_ARG(p->heads <= 65535 && p->nbatch <= 65535, "t2v_attn_bwd: heads/nbatch exceed grid limits");
   dim3 gq((p->Sq + 31) / 32, p->heads, p->nbatch);
-  if (use_wg_bwd(p->Sq))
+  if (use_wg2_bwd(p->Sq))
+    hipLaunchKernelGGL(attn_bwd_dq_wg2_kernel, dim3((p->Sq + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+  else if (use_wg_bwd(p->Sq))
     hipLaunchKernelGGL(attn_bwd_dq_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   dim3 gk((p->Sk + 31) / 32, p->heads, p->nbatch);
-  if (use_wg_bwd(p->Sk))
+  if (use_wg2_bwd(p->Sk))
+    hipLaunchKernelGGL(attn_bwd_dkdv_wg2_kernel, dim3((p->Sk + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+  else if (use_wg_bwd(p->Sk))
     hipLaunchKernelGGL(attn_bwd_dkdv_wg_kernel, dim3((p->Sk + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);

@@ -403,16 +403,11 @@ def _end_of_backward():
     join_side_stream()
 
 
-_SKIP_SIDE = os.environ.get("T2V_DEBUG_SKIP_WGRAD") == "1"      # timing experiment only: drops the factor-gradient launches
-
-
 def _fork_side(work, keep):
     """Run `work()` (factor-gradient launches) on the side stream, ordered after everything issued so far on the current
     stream.  The join is queued as an end-of-backward callback of the running autograd pass, so that whoever reads the
     gradients next (clip_grad_norm_, any optimizer, an all-reduce) sees them complete — also when the modules are driven by
     the reference's own train loop instead of DenoiseTrainer."""
-    if _SKIP_SIDE:
-        return
     side = _side_stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
