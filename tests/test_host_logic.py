@@ -357,27 +357,93 @@ def test_sampler_cfg_loop_with_a_stub_unet():
     assert len(calls) == 6 and all(c[0] == 2 and c[2] == 2 for c in calls) and calls[0][1] == 999
 
 
+@pytest.mark.parametrize("kind,ws,rotate", [("dpm", 3, False), ("dpm", 4, True), ("ddim", 2, True), ("dpm", 16, True)])
+def test_windowed_sampling_keeps_per_frame_solver_history(kind, ws, rotate):
+    """`diffuse` of inference.py:153-267: windows of `window_size` frames per UNet call, the multistep history kept per frame by
+    the caller, optional roll of the frame axis by a prime shift per timestep.  With a model that treats frames independently
+    (but is nonlinear and time dependent, so the second-order history matters) the windowed / rotated loop must reproduce the
+    whole-clip loop frame by frame."""
+    from t2v_amd.pipelines import TextToVideoSampler, primes_up_to
+    from t2v_amd.schedulers import DDIMScheduler, DPMSolverMultistepScheduler
+    assert primes_up_to(12) == [2, 3, 5, 7, 11] and primes_up_to(2) == [2, 3]
+    mk = (lambda: DDIMScheduler()) if kind == "ddim" else (lambda: DPMSolverMultistepScheduler())
+    sizes = []
+
+    class Stub:
+        config = type("c", (), {"in_channels": 4})()
+
+        def __call__(self, x, t, encoder_hidden_states=None):
+            sizes.append(x.shape[2])
+            return type("o", (), {"sample": torch.tanh(x * (0.3 + int(t[0]) / 2000.0)) + 0.1 * x})()
+
+    pe, ne = torch.randn(1, 77, 8), torch.zeros(1, 77, 8)
+    lat = torch.randn(1, 4, 10, 4, 4, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    kw = dict(num_inference_steps=9, guidance_scale=1.0, latents=lat.clone())
+    whole = TextToVideoSampler(Stub(), mk())(pe, ne, **kw)
+    n_whole = len(sizes)
+    win = TextToVideoSampler(Stub(), mk())(pe, ne, window_size=ws, rotate=rotate, generator=torch.Generator().manual_seed(4),
+                                          **dict(kw, latents=lat.clone()))
+    assert n_whole == 9 and set(sizes[:9]) == {10}
+    expect = [min(ws, 10 - s) for s in range(0, 10, min(ws, 10))] * 9
+    assert sizes[9:] == expect                                   # one UNet call per window and timestep, ragged last window
+    assert win.shape == whole.shape and torch.allclose(win, whole, atol=1e-10)
+
+
+def test_decode_latents_batches_frames_and_restores_the_clip_layout():
+    """inference.py:125-140: latents `(b c f h w)` -> frames `(b f)` -> `vae.decode(z / scaling_factor).sample` in batches of
+    `vae_batch_size` -> `(b c f H W)` fp32; and the sampler's `decode=True` returns that."""
+    from t2v_amd.models.vae import decode_latents
+    from t2v_amd.pipelines import TextToVideoSampler
+    seen = []
+
+    class StubVae:
+        config = type("c", (), {"scaling_factor": 0.5})()
+
+        def decode(self, z):
+            seen.append(tuple(z.shape))
+            up = z[:, :3].repeat_interleave(8, 2).repeat_interleave(8, 3)
+            return type("o", (), {"sample": up.half()})()
+
+    lat = torch.arange(2 * 4 * 5 * 2 * 2, dtype=torch.float32).reshape(2, 4, 5, 2, 2)
+    px = decode_latents(lat, StubVae(), batch_size=4)
+    assert seen == [(4, 4, 2, 2), (4, 4, 2, 2), (2, 4, 2, 2)]
+    assert px.shape == (2, 3, 5, 16, 16) and px.dtype == torch.float32
+    assert torch.equal(px[1, 2, 3, :8, :8], torch.full((8, 8), float(lat[1, 2, 3, 0, 0]) / 0.5))
+
+    class StubUnet:
+        config = type("c", (), {"in_channels": 4})()
+
+        def __call__(self, x, t, encoder_hidden_states=None):
+            return type("o", (), {"sample": torch.zeros_like(x)})()
+
+    out = TextToVideoSampler(StubUnet(), None, StubVae())(torch.zeros(1, 77, 8), None, num_frames=3, height=16, width=16,
+                                                          num_inference_steps=2, guidance_scale=1.0, decode=True,
+                                                          generator=torch.Generator().manual_seed(0))
+    assert out.shape == (1, 3, 3, 16, 16)
+    with pytest.raises(RuntimeError):
+        TextToVideoSampler(StubUnet())(torch.zeros(1, 77, 8), None, num_frames=1, height=16, width=16, num_inference_steps=1,
+                                      guidance_scale=1.0, decode=True, generator=torch.Generator().manual_seed(0))
+
+
 def test_vae_from_pretrained_accepts_a_full_diffusers_checkpoint(tmp_path):
     """`AutoencoderKL.from_pretrained(path, subfolder="vae")` (the call in the reference's load_primary_models,
     train.py:119-123) on a checkpoint in the stock diffusers layout: encoder + decoder + post_quant_conv, with the
-    ModelScope-era attention names query/key/value/proj_attn."""
+    ModelScope-era attention names query/key/value/proj_attn.  The decoder half is built because the checkpoint carries it
+    (`decode` serves inference.py:125-140); `with_decoder=False` loads the encoder half only (the train step)."""
     import json
     from safetensors.torch import save_file
     from t2v_amd.models.vae import AutoencoderKL
     cfg = dict(block_out_channels=(32, 64, 64, 64))
     torch.manual_seed(0)
-    ref = AutoencoderKL(**cfg)
+    ref = AutoencoderKL(with_decoder=True, **cfg)
     sd = {}
     for k, v in ref.state_dict().items():
         for a, b in ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn.")):
             if ".attentions." in k:
                 k = k.replace(a, b)
         sd[k] = v.clone()
-    assert any(".query." in k for k in sd)
-    sd["post_quant_conv.weight"] = torch.zeros(4, 4, 1, 1)
-    sd["post_quant_conv.bias"] = torch.zeros(4)
-    sd["decoder.conv_in.weight"] = torch.zeros(64, 4, 3, 3)
-    sd["decoder.mid_block.attentions.0.query.weight"] = torch.zeros(64, 64)
+    assert any(".query." in k for k in sd) and any(k.startswith("decoder.up_blocks.0.upsamplers.0.conv") for k in sd)
+    assert sum(k.startswith("decoder.up_blocks.") and ".resnets." in k and k.endswith("conv1.weight") for k in sd) == 12   # 4 x 3
     d = tmp_path / "vae"
     d.mkdir()
     save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
@@ -385,7 +451,12 @@ def test_vae_from_pretrained_accepts_a_full_diffusers_checkpoint(tmp_path):
         json.dump(dict(_class_name="AutoencoderKL", block_out_channels=list(cfg["block_out_channels"]), latent_channels=4), f)
     m = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
     a, b = ref.state_dict(), m.state_dict()
-    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert m.decoder is not None and set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    enc = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae", with_decoder=False)
+    assert enc.decoder is None and not any(k.startswith(("decoder.", "post_quant_conv.")) for k in enc.state_dict())
+    assert all(torch.equal(a[k], v) for k, v in enc.state_dict().items())
+    with pytest.raises(RuntimeError):
+        enc.decode(torch.zeros(1, 4, 4, 4))
     # an unknown encoder-side key still fails loudly (the load stays strict)
     sd["encoder.bogus.weight"] = torch.zeros(1)
     save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))

@@ -31,6 +31,44 @@ def test_vae_encode_matches_oracle():
     assert relerr(d.sample(eps=eps), mr + torch.exp(0.5 * lvr) * eps) < 5e-2
 
 
+def test_vae_decode_matches_oracle_and_round_trips_the_sampler():
+    """AutoencoderKL.decode (post_quant_conv -> decoder, the nearest-2x upsamples folded into the following conv's gather)
+    against the CPU restatement (`oracle/vae.py::AutoencoderKLDecoder`, call sites inference.py:125-140); then
+    `decode_latents` and the sampler's `decode=True` on the same weights (frames batched, clip layout restored)."""
+    from oracle.vae import AutoencoderKLDecoder, AutoencoderKLEncoder, decode_latents as oracle_decode_latents
+    from t2v_amd.models.vae import AutoencoderKL, decode_latents
+    from t2v_amd.pipelines import TextToVideoSampler
+    torch.manual_seed(3)
+    boc = (32, 64, 128, 128)
+    enc, dec = AutoencoderKLEncoder(block_out_channels=boc).eval(), AutoencoderKLDecoder(block_out_channels=boc).eval()
+    dut = AutoencoderKL(block_out_channels=boc, with_decoder=True)
+    sd = dict(enc.state_dict()); sd.update(dec.state_dict())
+    dut.load_state_dict(sd, strict=True)
+    dut = dut.cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(3, 4, 8, 12, generator=g)                    # non-square latent grid
+    with torch.no_grad():
+        pr = dec.decode(z)
+    pd = dut.decode(z.cuda()).sample
+    assert pd.shape == (3, 3, 64, 96) and pd.dtype == torch.float32
+    assert relerr(pd, pr) < 5e-2
+    lat = torch.randn(1, 4, 5, 8, 8, generator=g) * 0.18215
+    with torch.no_grad():
+        fr = oracle_decode_latents(lat, dec, batch_size=2)
+    fd = decode_latents(lat.cuda(), dut, batch_size=2)
+    assert fd.shape == (1, 3, 5, 64, 64) and relerr(fd, fr) < 5e-2
+
+    class Unet:                                                  # eps = 0: the sampler returns x0 = its start latents / alpha
+        config = type("c", (), {"in_channels": 4})()
+
+        def __call__(self, x, t, encoder_hidden_states=None):
+            return type("o", (), {"sample": torch.zeros_like(x)})()
+
+    out = TextToVideoSampler(Unet(), None, dut)(torch.zeros(1, 77, 8, device="cuda"), None, num_inference_steps=2, guidance_scale=1.0,
+                                                latents=lat.cuda(), decode=True, vae_batch_size=3)
+    assert out.shape == (1, 3, 5, 64, 64) and bool(torch.isfinite(out).all())
+
+
 def _build(r=4, lora_up_scale=0.05):
     from oracle.unet3d import UNet3DConditionModel as OUNet
     from oracle.vae import AutoencoderKLEncoder

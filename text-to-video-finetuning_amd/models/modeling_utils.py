@@ -47,9 +47,8 @@ class ModelMixinLite:
             if hasattr(m, "set_processor"):
                 m.set_processor(processor)
 
-    @classmethod
-    def _convert_checkpoint_keys(cls, sd):
-        """Hook: map a stock diffusers checkpoint onto this class's keys (identity by default; the load stays strict)."""
+    def _convert_checkpoint_keys(self, sd):
+        """Hook: map a stock diffusers checkpoint onto this model's keys (identity by default; the load stays strict)."""
         return sd
 
     @classmethod
@@ -72,20 +71,28 @@ class ModelMixinLite:
             torch.save(sd, os.path.join(save_directory, "diffusion_pytorch_model.bin"))
 
     @classmethod
-    def from_pretrained(cls, pretrained_model_path, subfolder=None, torch_dtype=None, **_):
+    def _ctor_kwargs_from_checkpoint(cls, sd):
+        """Hook: constructor arguments that follow from what the checkpoint holds (none by default)."""
+        return {}
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, torch_dtype=None, **overrides):
         d = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
         with open(os.path.join(d, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
-        import inspect
-        allowed = set(inspect.signature(cls.__init__).parameters) - {"self"}
-        model = cls(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items() if k in allowed})
         st = os.path.join(d, "diffusion_pytorch_model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file
             sd = load_file(st)
         else:
             sd = torch.load(os.path.join(d, "diffusion_pytorch_model.bin"), map_location="cpu")
-        sd = cls._convert_checkpoint_keys(sd)     # per-class key filter / remap of stock diffusers checkpoints
+        import inspect
+        allowed = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items() if k in allowed}
+        kw.update(cls._ctor_kwargs_from_checkpoint(sd))
+        kw.update({k: v for k, v in overrides.items() if k in allowed})
+        model = cls(**kw)
+        sd = model._convert_checkpoint_keys(sd)   # per-class key filter / remap of stock diffusers checkpoints
         model.load_state_dict(sd, strict=True)
         if torch_dtype is not None:
             model.to(torch_dtype)
