@@ -57,3 +57,14 @@ def train_step(unet, vae, batch, optimizer, max_grad_norm=1.0, acp=None):
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss.detach(), latents
+
+
+def sample_noise(latents, noise_strength, use_offset_noise=False, generator=None):
+    """train.py:349-358: eps ~ N(0,1) shaped like the latents; with offset noise, plus `noise_strength` x one N(0,1) draw per
+    (b, c, f), broadcast over the grid.  Draw ORDER matters for parity with a shared RNG stream: the full-size noise first,
+    then the (b,c,f,1,1) offsets."""
+    b, c, f = latents.shape[:3]
+    noise = torch.randn(latents.shape, generator=generator, device=latents.device, dtype=latents.dtype)
+    if use_offset_noise:
+        noise = noise + noise_strength * torch.randn(b, c, f, 1, 1, generator=generator, device=latents.device, dtype=latents.dtype)
+    return noise

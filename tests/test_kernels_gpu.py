@@ -439,6 +439,36 @@ def test_groupnorm_dropout_matches_masked_reference():
     assert relerr(y, y3) < TOL and relerr(xd.grad, xr.grad) < 3e-2
 
 
+def test_loralib_linear_input_dropout_on_the_lowrank_branch():
+    """loralib.Linear (stable_lora's Linear flavour, stable_lora/lora.py:199-207): y = x W^T + (lora_dropout(x) A^T B^T) * alpha/r.
+    The mask sits on the branch INPUT; forward and the three gradients against torch fp32 with the protocol mask."""
+    from oracle.dropout import keep_mask
+    from t2v_amd.models import leaves
+    from t2v_amd.stable_lora.lora import Linear
+    torch.manual_seed(5)
+    M, Cin, Cout, r, p = 200, 64, 96, 8, 0.25
+    lin = Linear(Cin, Cout, r=r, lora_alpha=16, lora_dropout=p).train()
+    with torch.no_grad():
+        lin.lora_B.copy_(torch.randn(Cout, r) * 0.2)
+    x = _bf(torch.randn(M, Cin)); dy = _bf(torch.randn(M, Cout))
+    leaves.set_dropout_seed(77)
+    seed = (77 * 1000003 + 1) & 0xFFFFFFFFFFFF
+    m = keep_mask(seed, M, Cin, p).float() / (1.0 - p)
+    xr = x.float().requires_grad_()
+    A, B = lin.lora_A.detach().clone().requires_grad_(), lin.lora_B.detach().clone().requires_grad_()
+    yr = xr @ _bf(lin.weight.detach()).float().t() + lin.bias.detach() + ((xr * m) @ A.t() @ B.t()) * lin.scaling
+    yr.backward(dy.float())
+    dev = lin.cuda()
+    xd = _dev(x)
+    y = leaves.run_layer(dev, xd)
+    y.backward(dy.cuda())
+    assert relerr(y, yr) < TOL and relerr(xd.grad, xr.grad) < 3e-2
+    assert relerr(dev.lora_A.grad, A.grad) < 3e-2 and relerr(dev.lora_B.grad, B.grad) < 3e-2
+    dev.eval()                                   # eval: dropout off (and loralib merges the delta into the weight)
+    y2 = leaves.run_layer(dev, _dev(x))
+    assert relerr(y2, x.float() @ (lin.weight.detach().float().cpu()).t() + lin.bias.detach().cpu()) < TOL
+
+
 def test_lora_branch_dropout_in_gemm_epilogue():
     """y = residual + dropout(scale * up(t)) (utils/lora.py:57-62 with dropout_p > 0): mask applied in the GEMM epilogue and
     re-applied to dy in backward."""

@@ -221,6 +221,100 @@ def test_trainable_text_encoder_two_pass_semantics():
             assert od[n].grad.abs().max() > 0 and e < 0.2       # bf16 UNet between the loss and the text states
 
 
+@pytest.mark.parametrize("offset", [False, True])
+def test_sample_noise_in_step_rng_and_offset_branch(offset):
+    """a2 (`sample_noise`, train.py:349-358) on the device RNG the step really uses: same seed -> the trainer's draw equals the
+    restated draw sequence bit for bit (full-size noise first, then one offset per (b,c,f)); the offset branch adds
+    strength^2 to the variance of every (b,c,f) plane mean; and a train step WITHOUT injected noise consumes that stream."""
+    from types import SimpleNamespace
+    from oracle.train_step import sample_noise as oracle_sample_noise
+    from t2v_amd.training import DenoiseTrainer
+    lat = torch.zeros(2, 4, 16, 32, 32, device="cuda")
+    cfg = SimpleNamespace(use_offset_noise=offset, offset_noise_strength=0.5)
+    torch.manual_seed(123)
+    n_native = DenoiseTrainer.sample_noise(cfg, lat)
+    torch.manual_seed(123)
+    n_ref = oracle_sample_noise(lat, 0.5, use_offset_noise=offset)
+    assert torch.equal(n_native, n_ref)
+    plane_mean = n_native.mean(dim=(3, 4))                       # (b,c,f): var = 1/(h*w) [+ strength^2]
+    want = 1.0 / 1024 + (0.25 if offset else 0.0)
+    got = float(plane_mean.var())
+    assert abs(got - want) < (0.12 if offset else 4e-4), (got, want)
+    assert abs(float(n_native.var()) - (1.0 + (0.25 if offset else 0.0))) < 0.08
+
+
+def test_train_step_without_injected_noise_draws_from_the_device_rng():
+    """The parity tests inject host-drawn noise / timesteps; the product path draws them in the step (train.py:752-760).  Same
+    seed -> same loss, different seed -> different loss, and the drawn timesteps stay inside [0, T)."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4)
+    dparams = [p for p in dunet.parameters() if p.requires_grad]
+    tr = DenoiseTrainer(dunet, dvae, dparams, lr=1e-4, use_offset_noise=True, offset_noise_strength=0.1)
+    batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=31, text_dim=64).items() if k not in ("noise", "timesteps", "vae_eps")}
+    losses = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        tr.opt.zero_grad()
+        losses.append(float(tr._fwd_bwd(batch)))
+    assert losses[0] == losses[1] and losses[0] != losses[2] and all(torch.isfinite(torch.tensor(losses)))
+
+
+def test_text_encoder_lora_trains_through_the_native_unet():
+    """Text-LoRA (`use_text_lora`, utils/lora.py:243-245, train.py:557-566,763-828): the handler injects LoRA into every Linear
+    of the CLIP encoder layers; in the two-pass step (pass 0 detached states, pass 1 frame 1 with live states) the loss gradient
+    must reach those factors through the native UNet's text cross-attention.  Oracle: the same recipe on CPU in fp32 with the
+    oracle's injector; the wrappers themselves run through stock torch ops inside CLIP."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from oracle.lora import inject_trainable_lora_extended as oinject
+    from oracle.train_step import finetune_unet_loss
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    from t2v_amd.utils.lora_handler import LoraHandler
+    ounet, ovae, dunet, dvae, _ = _build(r=4)
+    cfg = CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                         max_position_embeddings=77, bos_token_id=0, eos_token_id=999)
+    torch.manual_seed(5)
+    te_o = CLIPTextModel(cfg).eval()
+    te_d = copy.deepcopy(te_o)
+    te_o.requires_grad_(False); te_d.requires_grad_(False)
+    oinject(te_o, {"CLIPEncoderLayer"}, r=4)
+    LoraHandler(use_unet_lora=False, use_text_lora=True).add_lora_to_model(True, te_d, ["CLIPEncoderLayer"], dropout=0.0, r=4)
+    wrapped = [m for m in te_o.modules() if m.__class__.__name__ == "LoraInjectedLinear"]
+    assert len(wrapped) == 2 * 6 == sum(m.__class__.__name__ == "LoraInjectedLinear" for m in te_d.modules())   # q,k,v,out,fc1,fc2
+    g = torch.Generator().manual_seed(6)
+    for m in wrapped:                                           # a trained-looking state: lora_up away from its zero init
+        m.lora_up.weight.data = torch.randn(m.lora_up.weight.shape, generator=g) * 0.05
+    te_d.load_state_dict(te_o.state_dict(), strict=True)
+    for te in (te_o, te_d):
+        for m in te.modules():
+            if m.__class__.__name__ == "LoraInjectedLinear":
+                m.dropout.p = 0.0
+        assert all(p.requires_grad == ("lora" in n) for n, p in te.named_parameters())
+    te_d = te_d.cuda()
+    batch = synthetic_batch(4, 64, 64, seed=22, text_dim=64)
+    batch.pop("encoder_hidden_states")
+    batch["prompt_ids"] = torch.randint(0, 1000, (1, 1, 77), generator=g)
+    lo, _ = finetune_unet_loss(ounet, ovae, batch, text_encoder=te_o, text_trainable=True)
+    lo.backward()
+    dparams = [p for p in dunet.parameters() if p.requires_grad] + [p for p in te_d.parameters() if p.requires_grad]
+    tr = DenoiseTrainer(dunet, dvae, dparams, lr=1e-4, text_encoder=te_d)
+    tr.opt.zero_grad()
+    ld = tr._fwd_bwd({k: v.cuda() for k, v in batch.items()})
+    rel = abs(ld.item() - lo.item()) / abs(lo.item())
+    print(f"text-LoRA loss oracle {lo.item():.6f} native {ld.item():.6f} rel {rel:.2e}")
+    assert rel < 4e-3
+    od = dict(te_o.named_parameters())
+    checked = 0
+    for n, p in te_d.named_parameters():
+        if p.requires_grad:
+            assert od[n].grad is not None and od[n].grad.abs().max() > 0 and p.grad is not None
+            e = relerr(p.grad, od[n].grad)
+            assert e < 0.25, (n, e)                             # bf16 UNet between the loss and the text states
+            checked += 1
+    assert checked == 24
+
+
 def test_plain_backward_joins_factor_gradient_stream():
     """Driven the reference's way (loss.backward(); clip_grad_norm_; optimizer.step() — train.py:861-877) the side-stream
     factor-gradient launches must be joined by the end of backward: the end-of-backward callback leaves nothing pending."""

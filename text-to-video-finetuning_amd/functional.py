@@ -297,6 +297,30 @@ def launch_gemm_dropmask(dy, out, drop_p, drop_seed):
             drop_seed, nv.stream())
 
 
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout on a token matrix with the counter-based mask of the kernels (index = row * cols + col): the same call with
+    the same seed re-applies the mask to the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _mat(x, "x")
+        y = torch.empty(x.shape, dtype=BF16, device=x.device)
+        nv.call("t2v_dropout_mask", x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), x.shape[0], x.shape[1], p, seed, nv.stream())
+        ctx.args = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
+        dx = torch.empty(dy.shape, dtype=BF16, device=dy.device)
+        launch_gemm_dropmask(dy, dx, *ctx.args)
+        return dx, None, None
+
+
+def dropout(x, p, seed):
+    return _Dropout.apply(x, float(p), int(seed)) if p > 0.0 else x
+
+
 def _unprep_weight_grad(dwp, weight, cfg):
     """[Np, taps*Cin_p] fp32 (prepared order) -> gradient in the parameter's own layout/dtype."""
     n = weight.shape[0]

@@ -101,6 +101,19 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None):
                              drop_seed=_next_seed() if p > 0 else 0)
     if hasattr(mod, "lora_A") and hasattr(mod, "lora_B"):                               # loralib / stable_lora style
         w = mod.weight
+        merged = bool(getattr(mod, "merged", False))
+        if mod.__dict__.get("_t2v_merged_seen", merged) != merged:
+            # loralib folds / unfolds the delta with `weight.data +=` on train()/eval() (stable_lora/lora.py:112-117 upstream
+            # loralib), which leaves the tensor's version counter untouched: drop the cached bf16 copies of the old values
+            w.__dict__.pop("_t2v_prep", None)
+        mod.__dict__["_t2v_merged_seen"] = merged
+        p = _drop_p(getattr(mod, "lora_dropout", None))
+        if p > 0.0 and w.dim() == 2 and getattr(mod, "r", 0) > 0 and not getattr(mod, "merged", False):
+            # loralib Linear with an active lora_dropout: x W^T + (drop(x) A^T B^T) * scaling — the dropout sits on the INPUT of
+            # the low-rank branch, so the branch cannot be folded into the weight (the conv flavours have no dropout in forward)
+            y = F.conv_linear(x, w, mod.bias, cfg, rowbias, residual)
+            t = F.conv_linear(F.dropout(x, p, _next_seed()), mod.lora_A, None, LINEAR)
+            return F.conv_linear(t, mod.lora_B, None, LINEAR, None, y, alpha=float(mod.scaling))
         if getattr(mod, "r", 0) > 0 and not getattr(mod, "merged", False):
             delta = (mod.lora_B @ mod.lora_A)
             if w.dim() == 5:   # stable_lora Conv3d: view(out,in,k,k,1).mean(-2)  (stable_lora/lora.py:148-149,194)

@@ -55,7 +55,8 @@ class Linear(nn.Linear, LoRALayer):
     def train(self, mode=True):
         nn.Linear.train(self, mode)
         if self.merge_weights and self.r > 0 and self.merged == mode:
-            self.weight.data += self.delta() * (-1 if mode else 1)
+            self.weight.data += self.delta() * (-1 if mode else 1)     # (`.data +=` does not bump the version counter:
+            self.weight.__dict__.pop("_t2v_prep", None)                # drop the cached bf16 GEMM copies of the old values)
             self.merged = not mode
         return self
 
@@ -85,7 +86,8 @@ class Conv2d(nn.Conv2d, LoRALayer):
     def train(self, mode=True):
         nn.Conv2d.train(self, mode)
         if self.merge_weights and self.r > 0 and self.merged == mode:
-            self.weight.data += self.delta() * (-1 if mode else 1)
+            self.weight.data += self.delta() * (-1 if mode else 1)     # (`.data +=` does not bump the version counter:
+            self.weight.__dict__.pop("_t2v_prep", None)                # drop the cached bf16 GEMM copies of the old values)
             self.merged = not mode
         return self
 
