@@ -439,6 +439,62 @@ def test_groupnorm_dropout_matches_masked_reference():
     assert relerr(y, y3) < TOL and relerr(xd.grad, xr.grad) < 3e-2
 
 
+@pytest.mark.parametrize("flavour", ["linear", "conv2d", "conv3d"])
+def test_stable_lora_layers_against_the_reference_formulas(flavour):
+    """a22: the stable_lora layer flavours on the native path against the reference's forward FORMULAS written out here with
+    torch.nn.functional (not through the product's own module mirror):
+      Conv2d  (stable_lora/lora.py:119-126): conv2d(x, W + (B@A).view(W.shape) * alpha/r)
+      Conv3d  (:141-149,190-197): conv3d(x, W + mean((B@A).view(out, in, k, k, 1), dim=-2, keepdim) * alpha/r), kernel (k,1,1)
+      Linear  (loralib, :199-207): x W^T + (x A^T B^T) * alpha/r
+    forward, input gradient and both factor gradients."""
+    import torch.nn.functional as TF_
+    from t2v_amd.models import leaves
+    from t2v_amd.stable_lora import lora as SL
+    import t2v_amd.functional as F
+    torch.manual_seed(11)
+    r, alpha = 4, 8.0
+    if flavour == "linear":
+        mod = SL.Linear(64, 96, r=r, lora_alpha=alpha).train()
+        x5 = torch.randn(300, 64)
+    elif flavour == "conv2d":
+        mod = SL.Conv2d(32, 48, 3, r=r, lora_alpha=alpha, padding=1).train()
+        x5 = torch.randn(2, 32, 6, 10)
+    else:
+        mod = SL.Conv3d(32, 32, 3, r=r, lora_alpha=alpha, padding=(1, 0, 0)).train()
+        x5 = torch.randn(2, 32, 5, 4, 6)                         # (B, C, F, H, W)
+    with torch.no_grad():
+        mod.lora_B.copy_(torch.randn(mod.lora_B.shape) * 0.1)
+    x5 = _bf(x5)
+    W, b = _bf(mod.weight.detach()).float(), mod.bias.detach().float()
+    A, B = mod.lora_A.detach().clone().requires_grad_(), mod.lora_B.detach().clone().requires_grad_()
+    xr = x5.float().requires_grad_()
+    sc = alpha / r
+    if flavour == "linear":
+        yr = xr @ W.t() + b + (xr @ A.t() @ B.t()) * sc
+        xt, cfg, back = x5, F.LINEAR, (lambda m: m)
+        tok = lambda t: t
+    elif flavour == "conv2d":
+        yr = TF_.conv2d(xr, W + (B @ A).view(W.shape) * sc, b, padding=1)
+        n, c, h, w = x5.shape
+        cfg = F.ConvCfg.conv2d(n, h, w, 3, 1, 1)
+        tok = lambda t: t.permute(0, 2, 3, 1).reshape(n * h * w, -1)
+    else:
+        o, i, k = W.shape[:3]
+        yr = TF_.conv3d(xr, W + torch.mean((B @ A).view(o, i, k, k, 1), dim=-2, keepdim=True) * sc, b, padding=(1, 0, 0))
+        bsz, c, f, h, w = x5.shape
+        cfg = F.ConvCfg.conv3d_t(bsz, f, h * w)
+        tok = lambda t: t.permute(0, 2, 3, 4, 1).reshape(bsz * f * h * w, -1)
+    dy = _bf(torch.randn(yr.shape))
+    yr.backward(dy.float())
+    dev = mod.cuda()
+    xd = _dev(tok(x5))
+    y = leaves.run_layer(dev, xd, cfg)
+    y.backward(tok(dy).cuda().contiguous())
+    assert relerr(y, tok(yr.detach())) < TOL
+    assert relerr(xd.grad, tok(xr.grad)) < 3e-2
+    assert relerr(dev.lora_A.grad, A.grad) < 3e-2 and relerr(dev.lora_B.grad, B.grad) < 3e-2
+
+
 def test_loralib_linear_input_dropout_on_the_lowrank_branch():
     """loralib.Linear (stable_lora's Linear flavour, stable_lora/lora.py:199-207): y = x W^T + (lora_dropout(x) A^T B^T) * alpha/r.
     The mask sits on the branch INPUT; forward and the three gradients against torch fp32 with the protocol mask."""
