@@ -357,10 +357,14 @@ def join_side_stream():
 
 
 # ---- factor-gradient batching: the t2v_lora_wgrad descriptors of a backward pass are queued and run as a few
-# t2v_lora_wgrad_batch launches (every T2V_WGRAD_BATCH_LAYERS layers and at the end of the backward) instead of one ~15 us
-# kernel per layer.  T2V_WGRAD_BATCH=0 restores the per-layer launches.
-_wq = {"enabled": os.environ.get("T2V_WGRAD_BATCH", "1") != "0", "descs": [], "pool": [], "next": 0, "captured": [], "reserve": [],
-       "flush_at": int(os.environ.get("T2V_WGRAD_BATCH_LAYERS", "96"))}
+# t2v_lora_wgrad_batch launches instead of one ~15 us kernel per layer.  A batch is flushed IN STREAM ORDER on the launch
+# stream when it holds T2V_WGRAD_BATCH_LAYERS layers or T2V_WGRAD_BATCH_MB of operands (the operands are kept alive only until
+# their batch is enqueued — stream order makes the later reuse of their memory safe — so the extra residency is bounded: at the
+# C5 grid, holding every layer's x and dy to the end of the backward was +130 GB), and at the end of the backward.
+# T2V_WGRAD_BATCH=0 restores the per-layer launches (on the side stream).
+_wq = {"enabled": os.environ.get("T2V_WGRAD_BATCH", "1") != "0", "descs": [], "keep": [], "bytes": 0, "pool": [], "next": 0,
+       "captured": [], "reserve": [], "flush_at": int(os.environ.get("T2V_WGRAD_BATCH_LAYERS", "96")),
+       "flush_bytes": int(os.environ.get("T2V_WGRAD_BATCH_MB", "4096")) << 20}
 
 
 def _wgrad_launch(w, keep):
@@ -369,8 +373,9 @@ def _wgrad_launch(w, keep):
         nv.call("t2v_lora_wgrad", C.byref(w), nv.stream())
         return
     _wq["descs"].append(w)
-    _side["refs"].append(keep)               # operands stay alive until join_side_stream()
-    if len(_wq["descs"]) >= _wq["flush_at"]:
+    _wq["keep"].append(keep)
+    _wq["bytes"] += int(w.rows) * (int(w.N) + int(w.C)) * 2
+    if len(_wq["descs"]) >= _wq["flush_at"] or _wq["bytes"] >= _wq["flush_bytes"]:
         flush_wgrads()
     else:
         _join_at_end_of_backward()           # (outside a backward pass this flushes and joins at once)
@@ -393,10 +398,12 @@ def _wgrad_staging(nbytes, device):
         pair = (host, torch.empty(_WQ_BYTES, dtype=torch.uint8, device=device), None)
         _wq["captured"].append(pair)
         return pair
-    while len(_wq["reserve"]) < 32:          # stock for later captures
+    _wq["seen"] = _wq.get("seen", 0) + 1     # batches since the last end of a backward pass
+    want = max(32, 2 * max(_wq["seen"], _wq.get("per_pass", 0)) + 8)
+    while len(_wq["reserve"]) < want:        # stock for later captures: a captured step takes as many as an eager one flushes
         _wq["reserve"].append(torch.empty(_WQ_BYTES, dtype=torch.uint8, pin_memory=True))
     pool = _wq["pool"]
-    if len(pool) < 16:
+    if len(pool) < want // 2:                # a ring at least as long as one pass, so a reused slot is from an earlier step
         pool.append([torch.empty(_WQ_BYTES, dtype=torch.uint8, pin_memory=True),
                      torch.empty(_WQ_BYTES, dtype=torch.uint8, device=device), torch.cuda.Event()])
         return pool[-1]
@@ -420,11 +427,15 @@ def flush_wgrads():
     nv.call("t2v_lora_wgrad_batch", arr, n, host.data_ptr(), dev.data_ptr(), nbytes, nv.stream())
     if ev is not None:
         ev.record()
+    _wq["keep"].clear()                      # enqueued on the launch stream: later reuse of this memory is ordered behind it
+    _wq["bytes"] = 0
 
 
 def _end_of_backward():
     _side["cb"] = False
     join_side_stream()
+    _wq["per_pass"] = max(_wq.get("per_pass", 0), _wq.get("seen", 0))
+    _wq["seen"] = 0
 
 
 def _fork_side(work, keep):
@@ -615,10 +626,10 @@ def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=Non
                      out_mode=nv.OUT_F32_ATOMIC, alpha=scale, split_k=_split_k((kw + 63) // 64, M)))
         keep.append((tt, dtt))       # the launches above are asynchronous: hold the temporaries until the join
 
-    if _side["enabled"]:
+    if _side["enabled"] and not _wq["enabled"]:
         _fork_side(work, keep)
     else:
-        work()
+        work()                   # batched factor gradients are queued and flushed in stream order (no side stream)
 
 
 class _LoraMerged(torch.autograd.Function):
@@ -766,7 +777,7 @@ class _LoraGroupMerged(torch.autograd.Function):
                 w.alpha = scale
                 _wgrad_launch(w, (t, dt, x, keep))
 
-        if _side["enabled"]:
+        if _side["enabled"] and not _wq["enabled"]:
             _fork_side(work, keep)
         else:
             work()
@@ -875,7 +886,7 @@ class _LoraGroup(torch.autograd.Function):
                 w.alpha = scale
                 _wgrad_launch(w, (t, dt, x, keep))
 
-        if _side["enabled"]:
+        if _side["enabled"] and not _wq["enabled"]:
             _fork_side(wgrads, (keep, t, dt, x))
         else:
             wgrads()
