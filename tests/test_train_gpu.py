@@ -245,7 +245,7 @@ def test_sample_noise_in_step_rng_and_offset_branch(offset):
 
 def test_train_step_without_injected_noise_draws_from_the_device_rng():
     """The parity tests inject host-drawn noise / timesteps; the product path draws them in the step (train.py:752-760).  Same
-    seed -> same loss, different seed -> different loss, and the drawn timesteps stay inside [0, T)."""
+    seed -> same loss, different seed -> different loss."""
     from oracle.weights import synthetic_batch
     from t2v_amd.training import DenoiseTrainer
     _, _, dunet, dvae, _ = _build(r=4)
@@ -257,7 +257,9 @@ def test_train_step_without_injected_noise_draws_from_the_device_rng():
         torch.manual_seed(seed)
         tr.opt.zero_grad()
         losses.append(float(tr._fwd_bwd(batch)))
-    assert losses[0] == losses[1] and losses[0] != losses[2] and all(torch.isfinite(torch.tensor(losses)))
+    # (the loss reduction accumulates with fp32 atomics: equal up to summation order)
+    assert abs(losses[0] - losses[1]) < 1e-5 * abs(losses[0]) and abs(losses[0] - losses[2]) > 1e-4 * abs(losses[0])
+    assert all(torch.isfinite(torch.tensor(losses)))
 
 
 def test_text_encoder_lora_trains_through_the_native_unet():
