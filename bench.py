@@ -172,16 +172,25 @@ def gemm_roofline(trainer, batch):
     except Exception:   # noqa: BLE001
         kev = None
 
-    def timed(**kw):
+    def run_timed(call):
+        """-> (result, outer start, outer end, kernel-timestamp pair or None)"""
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         inner = kev.pair() if kev is not None else None
         s.record()
         if inner is not None:
-            lib.t2v_gemm_timing_events(inner[0], inner[1])
-        orig(**kw)
-        if inner is not None and not lib.t2v_gemm_timing_consumed():
+            lib.t2v_launch_timing_events(inner[0], inner[1])
+        r = call()
+        if inner is not None and not lib.t2v_launch_timing_consumed():
             inner = None
         e.record()
+        return r, s, e, inner
+
+    def dur(s, e, inner):        # kernel timestamps where the hook applied, the outer event pair otherwise
+        v = kev.ms(inner) if (kev is not None and inner is not None) else None
+        return v if v is not None and v > 0 else s.elapsed_time(e)
+
+    def timed(**kw):
+        _, s, e, inner = run_timed(lambda: orig(**kw))
         z = max(1, kw.get("batch", 1))
         flops = 2.0 * kw["M"] * kw["N"] * kw["K"] * z
         geom = kw.get("geom")
@@ -219,10 +228,7 @@ def gemm_roofline(trainer, batch):
     def timed_call(name, *a):
         if name not in ("t2v_attn_fwd", "t2v_attn_bwd", "t2v_lora_wgrad", "t2v_lora_wgrad_batch") and name not in NORM:
             return orig_call(name, *a)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        r = orig_call(name, *a)
-        e.record()
+        r, s, e, inner = run_timed(lambda: orig_call(name, *a))
         if name in NORM:
             pos, kind = NORM[name]
             if pos is None:                      # layernorm_fwd(x,ldx,y,ldy,rows,C,..) / bwd(x,ldx,dy,lddy,dx,lddx,rows,C,..)
@@ -236,7 +242,7 @@ def gemm_roofline(trainer, batch):
                 # algorithmic minimum: forward reads x once and writes y once (statistics from the same read);
                 # backward reads x and dy once and writes dx (+ reads the residual gradient it absorbs)
                 alg = {"t2v_gn_stats": 0, "t2v_gn_apply": 2, "t2v_gn_bwd_stats": 0, "t2v_gn_bwd_apply": 3 + (1 if addend else 0)}[name] * E * 2
-            norms.append((kind, alg, moved, s, e))
+            norms.append((kind, alg, moved, s, e, inner))
             return r
         if name == "t2v_lora_wgrad_batch":      # a[0] = array of descriptors, a[1] = their number: one launch for all of them
             fl = by = 0.0
@@ -245,21 +251,21 @@ def gemm_roofline(trainer, batch):
                 taps = d.geom.KH * d.geom.KW if d.conv else 1
                 fl += 2.0 * d.rp * (d.N + taps * d.C) * d.rows
                 by += (d.N + d.C) * d.rows * 2.0
-            wgrad.append((fl, by, s, e))
+            wgrad.append((fl, by, s, e, inner))
             wgrad_layers[0] += a[1]
             return r
         d = a[0]._obj
         if name == "t2v_lora_wgrad":      # each activation operand read once; fp32 factor gradients accumulated
             wgrad_layers[0] += 1
             taps = d.geom.KH * d.geom.KW if d.conv else 1
-            wgrad.append((2.0 * d.rp * (d.N + taps * d.C) * d.rows, (d.N + d.C) * d.rows * 2.0, s, e))
+            wgrad.append((2.0 * d.rp * (d.N + taps * d.C) * d.rows, (d.N + d.C) * d.rows * 2.0, s, e, inner))
             return r
         bh = float(d.nbatch) * d.heads * 64
         fwd = name == "t2v_attn_fwd"
         flops = 4.0 * bh * d.Sq * d.Sk * (1.0 if fwd else 2.5)           # QK^T + PV; backward: 5 products
         nbytes = bh * (2 * d.Sq + 2 * d.Sk) * 2.0 * (1.0 if fwd else 2.0)   # q,k,v,o (+ do,dq,dk,dv)
         kind = "text_cross" if d.Sk == 77 else ("temporal" if d.Sq == d.Sk and d.Sq <= 64 else "spatial")
-        attn.append((kind, flops, nbytes, s, e))
+        attn.append((kind, flops, nbytes, s, e, inner))
         return r
 
     F.launch_gemm = timed
@@ -277,9 +283,8 @@ def gemm_roofline(trainer, batch):
         F.launch_gemm_pair = orig_pair
         nv.call = orig_call
     out = {}
-    def kernel_ms(r):            # kernel timestamps where the hook applied, the outer event pair otherwise
-        v = kev.ms(r[5]) if (kev is not None and r[5] is not None) else None
-        return v if v is not None and v > 0 else r[1].elapsed_time(r[2])
+    def kernel_ms(r):
+        return dur(r[1], r[2], r[5])
 
     for name, sel in (("nn", True), ("kmajor", False)):
         rs = [r for r in records if r[3] == sel]
@@ -296,20 +301,20 @@ def gemm_roofline(trainer, batch):
     ns = {}
     if conv3d:
         ns["conv3d_3x1x1"] = both_roofs(sum(c[0] for c in conv3d), sum(c[1] for c in conv3d),
-                                        sum(kernel_ms((0, c[2], c[3], 0, 0, c[4])) for c in conv3d), len(conv3d))
+                                        sum(dur(c[2], c[3], c[4]) for c in conv3d), len(conv3d))
     if wgrad:
         ns["lora_factor_gradients"] = both_roofs(sum(c[0] for c in wgrad), sum(c[1] for c in wgrad),
-                                                 sum(c[2].elapsed_time(c[3]) for c in wgrad), len(wgrad))
+                                                 sum(dur(c[2], c[3], c[4]) for c in wgrad), len(wgrad))
         ns["lora_factor_gradients"]["layers"] = wgrad_layers[0]
     for kind in ("temporal", "spatial", "text_cross"):
         rs = [r for r in attn if r[0] == kind]
         if rs:
             ns[f"{kind}_attention_core"] = both_roofs(sum(r[1] for r in rs), sum(r[2] for r in rs),
-                                                      sum(r[3].elapsed_time(r[4]) for r in rs), len(rs))
+                                                      sum(dur(r[3], r[4], r[5]) for r in rs), len(rs))
     for kind in ("gn_fwd", "gn_bwd", "ln_fwd", "ln_bwd"):
         rs = [r for r in norms if r[0] == kind]
         if rs:
-            ms = sum(r[3].elapsed_time(r[4]) for r in rs)
+            ms = sum(dur(r[3], r[4], r[5]) for r in rs)
             alg, moved = sum(r[1] for r in rs), sum(r[2] for r in rs)
             ns[{"gn_fwd": "groupnorm_fwd(stats+apply)", "gn_bwd": "groupnorm_bwd(stats+apply)", "ln_fwd": "layernorm_fwd",
                 "ln_bwd": "layernorm_bwd"}[kind]] = {

@@ -111,11 +111,13 @@ int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
  * lines into the table and returns the number of entries accepted. */
 long long t2v_gemm_tune_export(char* buf, long long cap);
 int t2v_gemm_tune_import(const char* text);
-/* Measurement hook (bench.py's roofline): hand over a pair of hipEvent_t that the NEXT t2v_gemm call of this thread fills with
- * the kernel's own begin / end timestamps (hipExtLaunchKernelGGL) when it is a single NN (LDS-DMA) kernel; two-kernel split-K
- * launches and the K-major kernels leave them untouched.  t2v_gemm_timing_consumed() tells (1/0) and clears the pair. */
-int t2v_gemm_timing_events(void* start_event, void* stop_event);
-int t2v_gemm_timing_consumed(void);
+/* Measurement hook (bench.py's rooflines): hand over a pair of hipEvent_t that the NEXT instrumented entry point called by this
+ * thread fills with its kernel's own begin / end timestamps (hipExtLaunchKernelGGL): t2v_gemm (single-kernel NN launches; a
+ * two-kernel split-K launch leaves the pair untouched), t2v_gn_*, t2v_layernorm_*, t2v_attn_fwd, t2v_attn_bwd (start of its
+ * first kernel, end of its last), t2v_lora_wgrad(_batch).  t2v_launch_timing_consumed() tells whether the pair was filled (1/0)
+ * and clears it. */
+int t2v_launch_timing_events(void* start_event, void* stop_event);
+int t2v_launch_timing_consumed(void);
 /* Two independent K-major problems (a_trans = b_trans = 1, fp32 atomic output) in ONE launch: the two LoRA factor
  * gradients dU = s t^T dy and dD = s dt^T x_col of a wrapped layer (backward of utils/lora.py:57-62). */
 int t2v_gemm_pair(const T2VGemm* a, const T2VGemm* b, t2v_stream_t stream);

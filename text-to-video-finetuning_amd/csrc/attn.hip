@@ -1103,7 +1103,7 @@ extern "C" int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream) {
   if (int e = check_op("t2v_attn_fwd", "o", p->o)) return e;
   if (const int P = packed_seqs(*p)) {
     T2V_CHECK_ARG(p->heads <= 65535, "t2v_attn_fwd: heads exceed grid limits (%d)", p->heads);
-    hipLaunchKernelGGL(attn_fwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
+    T2V_LAUNCH(attn_fwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
                        p->Sq, P);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
@@ -1112,11 +1112,11 @@ extern "C" int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream) {
   T2V_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "t2v_attn_fwd: heads/nbatch exceed grid limits (%d, %d)", p->heads,
                 p->nbatch);
   if (use_wg(p->Sq)) {               // long query sequences: 4 waves share the K|V tiles through LDS
-    hipLaunchKernelGGL(attn_fwd_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+    T2V_LAUNCH(attn_fwd_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  T2V_LAUNCH(attn_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -1130,7 +1130,7 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
     if (int e = check_op("t2v_attn_bwd", names[i], *ops[i])) return e;
   if (const int P = packed_seqs(*p)) {
     T2V_CHECK_ARG(p->heads <= 65535, "t2v_attn_bwd: heads exceed grid limits (%d)", p->heads);
-    hipLaunchKernelGGL(attn_bwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
+    T2V_LAUNCH(attn_bwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
                        p->Sq, P);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
@@ -1138,19 +1138,19 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
   T2V_CHECK_ARG(p->heads <= 65535 && p->nbatch <= 65535, "t2v_attn_bwd: heads/nbatch exceed grid limits");
   dim3 gq((p->Sq + 31) / 32, p->heads, p->nbatch);
   if (use_wg2_bwd(p->Sq))
-    hipLaunchKernelGGL(attn_bwd_dq_wg2_kernel, dim3((p->Sq + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+    T2V_LAUNCH_FIRST(attn_bwd_dq_wg2_kernel, dim3((p->Sq + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else if (use_wg_bwd(p->Sq))
-    hipLaunchKernelGGL(attn_bwd_dq_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+    T2V_LAUNCH_FIRST(attn_bwd_dq_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
+    T2V_LAUNCH_FIRST(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   dim3 gk((p->Sk + 31) / 32, p->heads, p->nbatch);
   if (use_wg2_bwd(p->Sk))
-    hipLaunchKernelGGL(attn_bwd_dkdv_wg2_kernel, dim3((p->Sk + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+    T2V_LAUNCH_LAST(attn_bwd_dkdv_wg2_kernel, dim3((p->Sk + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else if (use_wg_bwd(p->Sk))
-    hipLaunchKernelGGL(attn_bwd_dkdv_wg_kernel, dim3((p->Sk + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
+    T2V_LAUNCH_LAST(attn_bwd_dkdv_wg_kernel, dim3((p->Sk + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);
+    T2V_LAUNCH_LAST(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

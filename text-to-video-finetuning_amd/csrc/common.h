@@ -1,6 +1,7 @@
 // common.h — shared device helpers for the gfx950 kernels (CDNA4, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "t2v_abi.h"
@@ -52,6 +53,29 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+
+
+// ---- measurement hook (t2v_launch_timing_events, include/t2v_abi.h): a pair of events that the NEXT instrumented entry point of
+// this thread fills with its kernel's own begin / end timestamps (hipExtLaunchKernelGGL) — what a kernel trace reports, without
+// the dispatch gap an event pair recorded around the call also contains.  Entry points that issue two kernels give the start
+// event to the first and the stop event to the last (T2V_LAUNCH_FIRST / T2V_LAUNCH_LAST).
+extern thread_local hipEvent_t t2v_time_start, t2v_time_stop;
+extern thread_local int t2v_time_used;
+template <typename F, typename... Args>
+inline void t2v_launch_timed(int which, F kern, dim3 grid, dim3 block, unsigned smem, hipStream_t s, Args... args) {
+  hipEvent_t e0 = (which & 1) ? t2v_time_start : nullptr, e1 = (which & 2) ? t2v_time_stop : nullptr;
+  if (e0 || e1) {
+    hipExtLaunchKernelGGL(kern, grid, block, smem, s, e0, e1, 0, args...);
+    if (which & 1) t2v_time_start = nullptr;
+    if (which & 2) t2v_time_stop = nullptr;
+    t2v_time_used = 1;
+  } else {
+    hipLaunchKernelGGL(kern, grid, block, smem, s, args...);
+  }
+}
+#define T2V_LAUNCH(kern, grid, block, smem, stream, ...) t2v_launch_timed(3, kern, grid, block, smem, stream, __VA_ARGS__)
+#define T2V_LAUNCH_FIRST(kern, grid, block, smem, stream, ...) t2v_launch_timed(1, kern, grid, block, smem, stream, __VA_ARGS__)
+#define T2V_LAUNCH_LAST(kern, grid, block, smem, stream, ...) t2v_launch_timed(2, kern, grid, block, smem, stream, __VA_ARGS__)
 
 void t2v_set_error(const char* fmt, ...);
 #define T2V_CHECK_ARG(cond, ...)          \

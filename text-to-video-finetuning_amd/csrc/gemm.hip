@@ -19,8 +19,6 @@
 #include <mutex>
 #include <unordered_map>
 #include <vector>
-#include <hip/hip_ext.h>
-
 #include "common.h"
 
 namespace {
@@ -911,12 +909,6 @@ bool lean_ok(const T2VGemm& p) {
   return true;
 }
 
-// Measurement hook (t2v_gemm_timing_events): a pair of events that the NEXT single-kernel NN launch of this thread fills with
-// the kernel's own begin / end timestamps (hipExtLaunchKernelGGL) — the duration a kernel trace reports, without the dispatch
-// gap an event pair recorded around the launch also contains.  Split-K launches (two kernels) leave the pair untouched.
-thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
-thread_local int g_time_used = 0;
-
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN>
 int launch_dma_v(const T2VGemm& p, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BK * 2;
@@ -930,13 +922,10 @@ int launch_dma_v(const T2VGemm& p, hipStream_t s) {
   }
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, p.ws_split > 1 ? p.ws_split : (p.batch > 1 ? p.batch : 1));
-  if (g_time_start && p.ws_split <= 1) {
-    hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), SMEM, s, g_time_start, g_time_stop, 0, p);
-    g_time_start = g_time_stop = nullptr;
-    g_time_used = 1;
-  } else {
+  if (p.ws_split <= 1)      // (a split-K launch is two kernels: it leaves the measurement hook's events untouched)
+    T2V_LAUNCH(kern, grid, dim3(WM * WN * 64), SMEM, s, p);
+  else
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), SMEM, s, p);
-  }
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -1210,16 +1199,19 @@ int check_gemm(const T2VGemm& p);
 
 // Two K-major (a_trans = b_trans = 1) problems with fp32 atomic output in one launch — the LoRA factor gradients
 // dU = s t^T dy and dD = s dt^T x_col of one layer (utils/lora.py:57-62 backward).
-extern "C" int t2v_gemm_timing_events(void* start, void* stop) {
-  g_time_start = (hipEvent_t)start;
-  g_time_stop = (hipEvent_t)stop;
-  g_time_used = 0;
+thread_local hipEvent_t t2v_time_start = nullptr, t2v_time_stop = nullptr;
+thread_local int t2v_time_used = 0;
+extern "C" int t2v_launch_timing_events(void* start, void* stop) {
+  t2v_time_start = (hipEvent_t)start;
+  t2v_time_stop = (hipEvent_t)stop;
+  t2v_time_used = 0;
   return T2V_OK;
 }
-// 1 if the launch issued since t2v_gemm_timing_events() filled the pair (clears the pair either way)
-extern "C" int t2v_gemm_timing_consumed(void) {
-  g_time_start = g_time_stop = nullptr;
-  return g_time_used;
+// 1 if an entry point called since t2v_launch_timing_events() filled the pair (clears the pair either way)
+extern "C" int t2v_launch_timing_consumed(void) {
+  const int used = t2v_time_used && !t2v_time_start && !t2v_time_stop;
+  t2v_time_start = t2v_time_stop = nullptr;
+  return used;
 }
 
 extern "C" int t2v_gemm_pair(const T2VGemm* pa, const T2VGemm* pb, t2v_stream_t stream) {

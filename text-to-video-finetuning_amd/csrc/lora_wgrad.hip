@@ -259,7 +259,7 @@ extern "C" int t2v_lora_wgrad_batch(const T2VLoraWgrad* descs, int nlayers, void
     t2v_set_error("t2v_lora_wgrad_batch: staging copy failed: %s", hipGetErrorString(hipGetLastError()));
     return T2V_ELAUNCH;
   }
-  hipLaunchKernelGGL(lora_wgrad_batch_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const Args*)device_table,
+  T2V_LAUNCH(lora_wgrad_batch_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const Args*)device_table,
                      (const int*)((const unsigned char*)device_table + args_bytes), njobs);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
@@ -276,11 +276,11 @@ extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
     const int taps = a.g.KH * a.g.KW;
     dim3 grid((unsigned)blocks[q]);
     if (taps == 1)
-      hipLaunchKernelGGL(lora_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+      T2V_LAUNCH(lora_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (taps == 3)
-      hipLaunchKernelGGL(lora_wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+      T2V_LAUNCH(lora_wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else
-      hipLaunchKernelGGL(lora_wgrad_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, a);
+      T2V_LAUNCH(lora_wgrad_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, a);
     T2V_CHECK_LAUNCH();
   }
   return T2V_OK;

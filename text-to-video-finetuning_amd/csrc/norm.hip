@@ -448,7 +448,7 @@ extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows
   dim3 grid(ns, ndomains);
   T2V_CHECK_ARG(ndomains <= GN_MAX_DOMAINS, "t2v_gn_stats: more than %d domains", GN_MAX_DOMAINS);
   unsigned* counters = (unsigned*)workspace;
-  hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0,
+  T2V_LAUNCH(gn_stats_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0,
                      rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, workspace + GN_MAX_DOMAINS, nullptr,
                      nullptr, sums, counters);
   T2V_CHECK_LAUNCH();
@@ -462,7 +462,7 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
   T2V_CHECK_ARG(x && y && sums && gamma && beta && ldy % 8 == 0, "t2v_gn_apply: bad args");
   T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_apply: bad domain grid");
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
-  hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
+  T2V_LAUNCH(gn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
                      0, (bf16_t*)y, ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed,
                      (const bf16_t*)nullptr, 0LL);
   T2V_CHECK_LAUNCH();
@@ -480,7 +480,7 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
   dim3 grid(ns, ndomains);
   T2V_CHECK_ARG(ndomains <= GN_MAX_DOMAINS, "t2v_gn_bwd_stats: more than %d domains", GN_MAX_DOMAINS);
   unsigned* counters = (unsigned*)workspace;
-  hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+  T2V_LAUNCH(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
                      lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, workspace + GN_MAX_DOMAINS, dgamma,
                      dbeta, bsums, counters);
   T2V_CHECK_LAUNCH();
@@ -497,7 +497,7 @@ extern "C" int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, lo
                 "t2v_gn_bwd_apply: bad args");
   T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_bwd_apply: bad domain grid");
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
-  hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+  T2V_LAUNCH(gn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,
                      silu, drop_p, drop_seed, (const bf16_t*)addend, ldadd);
   T2V_CHECK_LAUNCH();
@@ -509,7 +509,7 @@ extern "C" int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long lon
   T2V_CHECK_ARG(x && y && gamma && beta && rows > 0, "t2v_layernorm_fwd: bad args");
   T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_layernorm_fwd: need C%%8==0, C<=2048 (C=%d)", C);
   int grid = min((rows + 3) / 4, 16384);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
+  T2V_LAUNCH(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
                      rows, C, gamma, beta, eps, stats);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
@@ -524,7 +524,7 @@ extern "C" int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, l
                 "t2v_layernorm_bwd: need C%%8==0, C<=2048 (C=%d)", C);
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_layernorm_bwd: dgamma/dbeta must both be set or NULL");
   int grid = min((rows + 3) / 4, dgamma ? 1024 : 16384);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+  T2V_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
                      lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, dgamma, dbeta, (const bf16_t*)addend, ldadd);
   T2V_CHECK_LAUNCH();
   return T2V_OK;

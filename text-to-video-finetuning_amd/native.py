@@ -96,8 +96,8 @@ SYMBOLS = {
     "t2v_gemm_tune_export": ([C.c_char_p, c_ll], c_ll),
     "t2v_gemm_tune_import": ([C.c_char_p], c_int),
     "t2v_gemm_pair": ([C.POINTER(Gemm), C.POINTER(Gemm), c_void_p], c_int),
-    "t2v_gemm_timing_events": ([c_void_p, c_void_p], c_int),
-    "t2v_gemm_timing_consumed": ([], c_int),
+    "t2v_launch_timing_events": ([c_void_p, c_void_p], c_int),
+    "t2v_launch_timing_consumed": ([], c_int),
     "t2v_smallconv": ([C.POINTER(SmallConv), c_void_p], c_int),
     "t2v_gn_workspace_floats": ([c_int, c_int], c_ll),
     "t2v_gn_stats": ([c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
