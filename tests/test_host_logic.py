@@ -357,6 +357,26 @@ def test_sampler_cfg_loop_with_a_stub_unet():
     assert len(calls) == 6 and all(c[0] == 2 and c[2] == 2 for c in calls) and calls[0][1] == 999
 
 
+def test_aborted_backward_leaves_no_stale_factor_gradient_launches():
+    """The reference's loop swallows exceptions raised inside a step (train.py:881-883).  Factor-gradient descriptors queued by a
+    backward pass that died half-way point at operands that may be freed: the next zero_grad() drops them (with a warning)
+    instead of letting the next pass flush them."""
+    import warnings
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    w = nv.LoraWgrad()
+    w.rows, w.N, w.C = 10, 8, 8
+    F._wq["descs"].append(w)
+    F._wq["keep"].append(("operands",))
+    F._wq["bytes"] = 320
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert F.drop_pending_wgrads() == 1
+    assert len(rec) == 1 and "aborted backward" in str(rec[0].message)
+    assert not F._wq["descs"] and not F._wq["keep"] and F._wq["bytes"] == 0
+    assert F.drop_pending_wgrads() == 0
+
+
 @pytest.mark.parametrize("kind,ws,rotate", [("dpm", 3, False), ("dpm", 4, True), ("ddim", 2, True), ("dpm", 16, True)])
 def test_windowed_sampling_keeps_per_frame_solver_history(kind, ws, rotate):
     """`diffuse` of inference.py:153-267: windows of `window_size` frames per UNet call, the multistep history kept per frame by

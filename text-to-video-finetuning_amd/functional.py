@@ -415,6 +415,20 @@ def _wgrad_staging(nbytes, device):
     return slot
 
 
+def drop_pending_wgrads():
+    """Discard factor-gradient descriptors that were queued by a backward pass which never reached its end (an exception in the
+    middle of it — the reference's loop swallows those, train.py:881-883): their operands may be gone.  Called at zero_grad()."""
+    n = len(_wq["descs"])
+    if n:
+        _wq["descs"].clear()
+        _wq["keep"].clear()
+        _wq["bytes"] = 0
+        _side["cb"] = False
+        import warnings
+        warnings.warn(f"t2v_amd: dropped {n} queued LoRA factor-gradient launches of an aborted backward pass")
+    return n
+
+
 def flush_wgrads():
     descs = _wq["descs"]
     n = len(descs)
