@@ -17,7 +17,8 @@ FAMILIES = [("gemm_kernel_dma", "gemm_kernel_dma<...> (Linear / Conv2d / Conv3d 
             ("lora_merge", "lora_merge_kernel"), ("gn_stats_kernelILb0", "gn_stats (forward)"), ("gn_stats_kernelILb1", "gn_stats (backward)"),
             ("gn_apply_kernelILb0", "gn_apply (forward)"), ("gn_apply_kernelILb1", "gn_apply (backward)"),
             ("ln_fwd", "ln_fwd"), ("ln_bwd", "ln_bwd"), ("attn_fwd_packed", "attn_fwd_packed (temporal)"),
-            ("attn_bwd_packed", "attn_bwd_packed (temporal)"), ("attn_fwd_kernel", "attn_fwd (spatial / text)"),
+            ("attn_bwd_packed", "attn_bwd_packed (temporal)"), ("attn_fwd_wg", "attn_fwd_wg (spatial, shared K/V tiles)"),
+            ("attn_fwd_kernel", "attn_fwd (spatial / text)"),
             ("attn_bwd_dq", "attn_bwd_dq"), ("attn_bwd_dkdv", "attn_bwd_dkdv"), ("geglu_fwd", "geglu_fwd"), ("geglu_bwd", "geglu_bwd")]
 
 
