@@ -497,7 +497,7 @@ def main():
         batch["latents"] = (torch.randn(1, 4, frames, H // 8, W // 8, generator=g) * 0.18215 * 4.0).to(dev)
         del batch["pixel_values"]
 
-    use_graph = not args.no_graph and not args.dropout       # active dropout draws fresh masks per step: eager launches
+    use_graph = not args.no_graph             # active dropout is captured too: the device-side dropout epoch moves the masks
     text_mode = "clip-in-step" if text_encoder is not None else "synthetic"
     if use_graph:
         try:

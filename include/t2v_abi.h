@@ -104,8 +104,16 @@ typedef struct {
    * panels stay in its L2, every XCD streams the whole weight matrix); 1: an XCD owns a run of N-tiles x all M-tiles (each
    * weight column block is fetched by ONE XCD — the layers whose weights outweigh their activations: 8x8 / 4x4 levels) */
   int raster_n;
+  /* dropout epoch: device counter folded into drop_seed (see t2v_set_dropout_epoch); NULL = the process-wide one (or none) */
+  const unsigned long long* drop_epoch;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
+/* Dropout epoch.  Every dropout-capable entry point (t2v_gemm epilogue, t2v_gn_apply / t2v_gn_bwd_*, t2v_lowrank_update_drop,
+ * t2v_dropout_mask) takes its seed BY VALUE, so a captured HIP graph would replay the same masks every step.  With an epoch
+ * registered, the launches issued afterwards also carry the ADDRESS of this 8-byte device counter and use
+ * seed + (*counter) * 0x9E3779B97F4A7C15; the caller bumps the counter once per optimisation step (inside the graph), forward
+ * and backward of one step read the same value.  NULL unregisters (seeds are used as given: the protocol of oracle/dropout.py). */
+int t2v_set_dropout_epoch(const unsigned long long* device_counter);
 /* Tuned tile table: text, one line per problem signature ("M N K a_mode n_split out_mode has_res batch KH KW sy tdiv up C
  * tile stages split").  export: writes at most `cap` bytes (NUL-terminated) and returns the size needed; import: merges the
  * lines into the table and returns the number of entries accepted. */

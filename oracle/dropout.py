@@ -28,6 +28,12 @@ def keep_mask(seed, rows, cols, p):
     return torch.from_numpy((u >= np.float32(p)).reshape(rows, cols))
 
 
+def effective_seed(seed, epoch):
+    """Seed of a launch issued while a dropout epoch is registered (`t2v_set_dropout_epoch`, csrc/common.h `eff_seed`):
+    seed + epoch * 0x9E3779B97F4A7C15 (mod 2^64); epoch = the value of the device counter when the kernel runs."""
+    return (int(seed) + int(epoch) * 0x9E3779B97F4A7C15) & _M64
+
+
 def apply(x, seed, p):
     """Inverted dropout of a [rows, cols] matrix with the protocol's mask."""
     m = keep_mask(seed, x.shape[0], x.shape[1], p).to(x.dtype)

@@ -420,6 +420,57 @@ def test_dropout_mask_protocol_matches_cpu_restatement():
     assert torch.allclose(y.cpu().float()[keep], torch.tensor(1.0 / (1.0 - p)).to(torch.bfloat16).float())
 
 
+def test_dropout_epoch_offsets_every_dropout_kernel_like_the_restatement():
+    """t2v_set_dropout_epoch: launches issued while a device counter is registered use seed + counter * 0x9E3779B97F4A7C15 — the
+    counter is read when the kernel RUNS (a captured graph sees its current value) — for the mask kernel, the GroupNorm epilogue
+    and the GEMM epilogue; unregistering restores the plain protocol."""
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    from oracle.dropout import effective_seed, keep_mask
+    rows, cols, p, seed = 96, 320, 0.3, 0xABCDEF12345
+    ctr = torch.tensor([7], dtype=torch.int64, device="cuda")
+    x = torch.ones(rows, cols, dtype=torch.bfloat16, device="cuda")
+    try:
+        nv.call("t2v_set_dropout_epoch", ctr.data_ptr())
+        y7 = torch.empty_like(x)
+        nv.call("t2v_dropout_mask", x.data_ptr(), cols, y7.data_ptr(), cols, rows, cols, p, seed, nv.stream())
+        g = torch.cuda.CUDAGraph()                               # the captured launch carries the ADDRESS: replays follow the counter
+        yg = torch.empty_like(x)
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            nv.call("t2v_dropout_mask", x.data_ptr(), cols, yg.data_ptr(), cols, rows, cols, p, seed, nv.stream())
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g):
+            nv.call("t2v_dropout_mask", x.data_ptr(), cols, yg.data_ptr(), cols, rows, cols, p, seed, nv.stream())
+        masks = []
+        for e in (8, 9):
+            ctr.fill_(e)
+            g.replay()
+            torch.cuda.synchronize()
+            masks.append((yg.cpu() != 0).clone())
+        gm = torch.randn(cols); bt = torch.randn(cols)          # GroupNorm(+SiLU)+dropout epilogue under epoch 9
+        xin = _bf(torch.randn(2 * 48, cols))
+        yn = F.group_norm(xin.cuda(), gm.cuda(), bt.cuda(), 32, 1e-5, True, 2, p, seed)
+        td = _bf(torch.randn(rows, 16)); w = _bf(torch.randn(cols, 16) * 0.3)
+        yl = F.conv_linear(td.cuda(), w.cuda(), None, F.LINEAR, None, torch.zeros(rows, cols, dtype=torch.bfloat16, device="cuda"),
+                           alpha=1.0, drop_p=p, drop_seed=seed)
+    finally:
+        nv.call("t2v_set_dropout_epoch", None)
+    y0 = torch.empty_like(x)
+    nv.call("t2v_dropout_mask", x.data_ptr(), cols, y0.data_ptr(), cols, rows, cols, p, seed, nv.stream())
+    assert torch.equal(y7.cpu() != 0, keep_mask(effective_seed(seed, 7), rows, cols, p))
+    assert torch.equal(masks[0], keep_mask(effective_seed(seed, 8), rows, cols, p))
+    assert torch.equal(masks[1], keep_mask(effective_seed(seed, 9), rows, cols, p)) and not torch.equal(masks[0], masks[1])
+    assert torch.equal(y0.cpu() != 0, keep_mask(seed, rows, cols, p))
+    k9 = keep_mask(effective_seed(seed, 9), rows, cols, p)
+    ref = TF.silu(TF.group_norm(xin.float().view(2, 48, cols).permute(0, 2, 1), 32, gm, bt, 1e-5)).permute(0, 2, 1).reshape(96, cols)
+    nz = ref.abs() > 1e-3                                       # (a SiLU output that rounds to zero says nothing about the mask)
+    assert torch.equal((yn.detach().cpu() != 0)[nz], k9[nz])
+    prod = td.float() @ w.float().t()
+    nz = prod.abs() > 1e-3
+    assert torch.equal((yl.detach().cpu() != 0)[nz], k9[nz])
+
+
 def test_groupnorm_dropout_matches_masked_reference():
     """GroupNorm+SiLU+Dropout (TemporalConvLayer conv2-4, models/unet_3d_blocks.py:312…) with the protocol mask, fwd + bwd."""
     import t2v_amd.functional as F

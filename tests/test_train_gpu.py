@@ -262,6 +262,39 @@ def test_train_step_without_injected_noise_draws_from_the_device_rng():
     assert all(torch.isfinite(torch.tensor(losses)))
 
 
+def test_captured_step_with_active_dropout_draws_fresh_masks_every_replay():
+    """The reference's default train mode keeps dropout on (LoRA 0.1, TemporalConvLayer 0.1).  Seeds are frozen into a captured
+    graph; the device-side dropout epoch that the step bumps first thing moves the masks: replays of the SAME batch give
+    different losses, and a replay equals the eager step run at the same epoch."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.models import leaves
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4)
+    n = 0
+    for m in dunet.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.3
+            n += 1
+    dunet.train()
+    assert n > 0
+    dparams = [p for p in dunet.parameters() if p.requires_grad]
+    tr = DenoiseTrainer(dunet, dvae, dparams, lr=0.0)            # lr 0: the weights stay put, only the masks move
+    batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=41, text_dim=64).items()}
+    tr.capture(batch, warmup=1)
+    losses = [float(tr.replay_step()) for _ in range(3)]
+    assert len({round(l, 6) for l in losses}) == 3, losses      # three replays, three mask sets
+    # eager step at a chosen epoch twice -> identical; (the graph's frozen host seeds differ from a fresh eager pass's, so only
+    # the eager/eager comparison is exact)
+    outs = []
+    for _ in range(2):
+        leaves.set_dropout_seed(0x5EED)
+        tr._drop_epoch.fill_(1000)
+        tr.opt.zero_grad()
+        outs.append(float(tr._fwd_bwd(batch)))
+    assert abs(outs[0] - outs[1]) < 1e-5 * abs(outs[0])
+    assert int(tr._drop_epoch) == 1001
+
+
 def test_text_encoder_lora_trains_through_the_native_unet():
     """Text-LoRA (`use_text_lora`, utils/lora.py:243-245, train.py:557-566,763-828): the handler injects LoRA into every Linear
     of the CLIP encoder layers; in the two-pass step (pass 0 detached states, pass 1 frame 1 with live states) the loss gradient

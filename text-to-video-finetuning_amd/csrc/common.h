@@ -34,6 +34,14 @@ __device__ __forceinline__ bf16x8 pack8bf(const float (&v)[8]) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// Dropout epoch (t2v_set_dropout_epoch, include/t2v_abi.h): an optional DEVICE counter folded into every dropout seed.  Seeds
+// reach the kernels by value, so a captured HIP graph would replay the same masks every step; with the epoch the captured
+// launches carry the counter's ADDRESS and the step bumps its value (forward and backward of one step read the same value).
+extern const unsigned long long* t2v_drop_epoch;      // host-side: what the next launches pass to their kernels (may be null)
+__device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, const unsigned long long* epoch) {
+  return epoch ? seed + *epoch * 0x9E3779B97F4A7C15ull : seed;
+}
+
 // counter-based dropout keep decision: splitmix64 of (seed, element index)
 __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, float p) {
   unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restr
 
 __global__ __launch_bounds__(256) void dropout_mask_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
                                                             long long ldy, long long rows, int cols, float p,
-                                                            unsigned long long seed) {
+                                                            unsigned long long seed_in, const unsigned long long* __restrict__ epoch) {
+  const unsigned long long seed = eff_seed(seed_in, epoch);
   const float ks = 1.f / (1.f - p);
   const long long n = rows * cols;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -219,7 +220,9 @@ template <int R>
 __global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict__ y, long long ldy, const bf16_t* __restrict__ t,
                                                               long long ldt, const bf16_t* __restrict__ U, long long ldu,
                                                               long long M, int N, float scale, int rows_per_block,
-                                                              float drop_p, unsigned long long drop_seed) {
+                                                              float drop_p, unsigned long long drop_seed_in,
+                                                              const unsigned long long* __restrict__ drop_epoch) {
+  const unsigned long long drop_seed = drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c0 = (blockIdx.x * 4 + w) * 32;
   if (c0 >= N) return;
@@ -471,10 +474,16 @@ extern "C" int t2v_softmax_rows(const void* x, long long ldx, void* y, long long
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
+const unsigned long long* t2v_drop_epoch = nullptr;
+extern "C" int t2v_set_dropout_epoch(const unsigned long long* device_counter) {
+  t2v_drop_epoch = device_counter;
+  return T2V_OK;
+}
+
 extern "C" int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long long rows, int cols, float p,
                                 unsigned long long seed, t2v_stream_t s) {
   T2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "t2v_dropout_mask: bad args");
-  LAUNCH1D(dropout_mask_kernel, rows * cols, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, p, seed);
+  LAUNCH1D(dropout_mask_kernel, rows * cols, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, p, seed, t2v_drop_epoch);
 }
 static int lowrank_update_impl(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M,
                                int N, int r, float scale, float drop_p, unsigned long long drop_seed, t2v_stream_t s) {
@@ -489,7 +498,7 @@ static int lowrank_update_impl(void* y, long long ldy, const void* t, long long 
   dim3 grid(ncb, (unsigned)((M + rpb - 1) / rpb));
 #define T2V_LRU(RR)                                                                                                      \
   hipLaunchKernelGGL(lowrank_update_kernel<RR>, grid, dim3(256), 0, (hipStream_t)s, (bf16_t*)y, ldy, (const bf16_t*)t, ldt, \
-                     (const bf16_t*)U, ldu, M, N, scale, rpb, drop_p, drop_seed)
+                     (const bf16_t*)U, ldu, M, N, scale, rpb, drop_p, drop_seed, t2v_drop_epoch)
   if (r == 8) T2V_LRU(8);
   else if (r == 16) T2V_LRU(16);
   else if (r == 24) T2V_LRU(24);

@@ -80,10 +80,11 @@ __device__ __forceinline__ void finish_chunk(const T2VGemm& p, float (&v)[8], lo
       break;
     }
     if (p.drop_p > 0.f) {
+      const unsigned long long seed = eff_seed(p.drop_seed, p.drop_epoch);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         unsigned long long idx = ((unsigned long long)z * M + row) * N + col + e;
-        v[e] = drop_keep(p.drop_seed, idx, p.drop_p) ? v[e] * keep_scale : 0.f;
+        v[e] = drop_keep(seed, idx, p.drop_p) ? v[e] * keep_scale : 0.f;
       }
     }
     if (bias) {
@@ -1326,7 +1327,8 @@ extern "C" int t2v_gemm_tune_import(const char* text) {
 
 extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
   T2V_CHECK_ARG(pp != nullptr, "t2v_gemm: null descriptor");
-  const T2VGemm& p = *pp;
+  T2VGemm p = *pp;
+  if (!p.drop_epoch) p.drop_epoch = t2v_drop_epoch;          // the step's dropout epoch (null outside a trainer step)
   if (int e = check_gemm(p)) return e;
   hipStream_t s = (hipStream_t)stream;
   static const bool env_init = [] {

@@ -17,12 +17,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                                                         const bf16_t* __restrict__ dy, long long lddy,
                                                         int rows_per_domain, int C, int G, const float* __restrict__ sums,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, int silu, float drop_p, unsigned long long drop_seed,
+                                                        float eps, int silu, float drop_p, unsigned long long drop_seed_in,
+                                                        const unsigned long long* __restrict__ drop_epoch,
                                                         float* __restrict__ partial, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, float* __restrict__ out,
                                                         unsigned* __restrict__ counters) {
   __shared__ float sval[256 * 17];
   __shared__ int s_last;   // per-thread (8 sums, 8 second sums), row stride 17 to dodge bank conflicts
+  const unsigned long long drop_seed = drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull;
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -190,8 +192,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                         bf16_t* __restrict__ y, long long ldy, int rows_per_domain, int C, int G,
                                                         const float* __restrict__ sums, const float* __restrict__ bsums,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, int silu, float drop_p, unsigned long long drop_seed,
+                                                        float eps, int silu, float drop_p, unsigned long long drop_seed_in,
+                                                        const unsigned long long* __restrict__ drop_epoch,
                                                         const bf16_t* __restrict__ addend, long long ldadd) {
+  const unsigned long long drop_seed = drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull;
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -449,7 +453,7 @@ extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows
   T2V_CHECK_ARG(ndomains <= GN_MAX_DOMAINS, "t2v_gn_stats: more than %d domains", GN_MAX_DOMAINS);
   unsigned* counters = (unsigned*)workspace;
   T2V_LAUNCH(gn_stats_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0,
-                     rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, workspace + GN_MAX_DOMAINS, nullptr,
+                     rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, (const unsigned long long*)nullptr, workspace + GN_MAX_DOMAINS, nullptr,
                      nullptr, sums, counters);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
@@ -463,7 +467,7 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
   T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_apply: bad domain grid");
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
   T2V_LAUNCH(gn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
-                     0, (bf16_t*)y, ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed,
+                     0, (bf16_t*)y, ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch,
                      (const bf16_t*)nullptr, 0LL);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
@@ -481,7 +485,7 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
   T2V_CHECK_ARG(ndomains <= GN_MAX_DOMAINS, "t2v_gn_bwd_stats: more than %d domains", GN_MAX_DOMAINS);
   unsigned* counters = (unsigned*)workspace;
   T2V_LAUNCH(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, workspace + GN_MAX_DOMAINS, dgamma,
+                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch, workspace + GN_MAX_DOMAINS, dgamma,
                      dbeta, bsums, counters);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
@@ -499,7 +503,7 @@ extern "C" int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, lo
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
   T2V_LAUNCH(gn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,
-                     silu, drop_p, drop_seed, (const bf16_t*)addend, ldadd);
+                     silu, drop_p, drop_seed, t2v_drop_epoch, (const bf16_t*)addend, ldadd);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

@@ -58,6 +58,7 @@ class Gemm(C.Structure):
         ("B2", c_void_p), ("ldb2", c_ll), ("n_split", c_int), ("D2", c_void_p), ("ldd2", c_ll),
         ("b_tapflip", c_int), ("b2_k0", c_int), ("b2_klen", c_int),
         ("workspace", c_void_p), ("workspace_bytes", C.c_size_t), ("ws_split", c_int), ("raster_n", c_int),
+        ("drop_epoch", c_void_p),
     ]
 
 
@@ -93,6 +94,7 @@ SYMBOLS = {
     "t2v_abi_version": ([], c_int),
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_set_dropout_epoch": ([c_void_p], c_int),
     "t2v_gemm_tune_export": ([C.c_char_p, c_ll], c_ll),
     "t2v_gemm_tune_import": ([C.c_char_p], c_int),
     "t2v_gemm_pair": ([C.POINTER(Gemm), C.POINTER(Gemm), c_void_p], c_int),

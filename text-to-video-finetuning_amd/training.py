@@ -171,6 +171,11 @@ class DenoiseTrainer:
             self.scheduler.rescale_betas()         # train.py:689-690 (betas only; see schedulers.enforce_zero_terminal_snr)
         self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet)
         self.pg, self.world = process_group, world_size
+        self.rank = 0
+        if world_size > 1:
+            import torch.distributed as dist
+            self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self._drop_epoch = None                    # device-side dropout epoch (ranks start 2^32 apart: different masks per rank)
         self._graph = None
         self._static = None
 
@@ -247,16 +252,26 @@ class DenoiseTrainer:
         return self._aux_stream
 
     def _fwd_bwd(self, batch):
-        # bf16 factor copies + merged weights W_eff for this step (one cast + one merge kernel, HBM-bound): on the auxiliary
-        # stream, beside the MFMA-bound VAE encode; loss_fn joins it before the UNet
-        aux = self._aux()
-        aux.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(aux):
-            self.opt.refresh_bf16()
-        loss = self.loss_fn(batch)
-        loss.backward()
-        from .functional import join_side_stream
-        join_side_stream()                 # factor-gradient launches (side stream) complete before clip/AdamW/all-reduce
+        # Dropout epoch: seeds reach the kernels by value (host counter, models/leaves.py::_next_seed), which a captured graph
+        # would freeze; the launches of this step therefore also carry the address of a device counter that the step bumps
+        # first thing (one captured add), so every replay draws fresh masks while forward and backward of a step agree.
+        if self._drop_epoch is None:
+            self._drop_epoch = torch.full((1,), (int(self.rank) << 32) + 1, dtype=torch.int64, device=self.opt.flat_p.device)
+        self._drop_epoch += 1
+        nv.call("t2v_set_dropout_epoch", self._drop_epoch.data_ptr())
+        try:
+            # bf16 factor copies + merged weights W_eff for this step (one cast + one merge kernel, HBM-bound): on the
+            # auxiliary stream, beside the MFMA-bound VAE encode; loss_fn joins it before the UNet
+            aux = self._aux()
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux):
+                self.opt.refresh_bf16()
+            loss = self.loss_fn(batch)
+            loss.backward()
+            from .functional import join_side_stream
+            join_side_stream()             # the last factor-gradient batch is enqueued before clip / AdamW / all-reduce
+        finally:
+            nv.call("t2v_set_dropout_epoch", None)
         return loss.detach()
 
     def _exchange_and_update(self, loss):
@@ -274,14 +289,8 @@ class DenoiseTrainer:
 
     # ---- HIP-graph replay of forward+backward (static shapes)
     def capture(self, batch, warmup=2):
-        # Dropout seeds are host-side counters passed to the kernels BY VALUE (models/leaves.py::_next_seed): a captured
-        # graph would replay the same masks every step.  Active dropout therefore runs eagerly (train_step).
-        active = [n for mod in (self.unet, self.text_encoder) if mod is not None for n, m in mod.named_modules()
-                  if isinstance(m, torch.nn.Dropout) and m.training and m.p > 0]
-        if active:
-            raise RuntimeError(f"DenoiseTrainer.capture(): {len(active)} active nn.Dropout modules (e.g. {active[0]}); a HIP graph "
-                               "would freeze their masks. Use train_step() (eager) with dropout on, or the reference's "
-                               "eval_train mode (train.py:779-781) for graph replay.")
+        # Active dropout is captured too: the seeds frozen into the graph are offset per replay by the device-side dropout
+        # epoch that `_fwd_bwd` bumps inside the captured region (t2v_set_dropout_epoch).
         static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
