@@ -1,4 +1,8 @@
-"""TEMP probe driver: per-wave cycle split of the GEMM K loop (wait+barrier / DMA issue / fragment reads + MFMA)."""
+"""Driver of the K-loop cycle probe (profiles/r02_gemm_kloop_probe.txt): per-wave cycle split of the GEMM K loop into
+wait+barrier / LDS-DMA issue / fragment reads + MFMA.  It needs a TEMPORARY instrumentation of csrc/gemm.hip that is not part of the
+build: a `__device__ unsigned long long g_probe[8]`, clock64() stamps before the counted s_waitcnt, after the s_barrier, after
+issue() and after compute() of `gemm_kernel_dma`'s K loop (lane 0 of every wave atomically adds its sums and iteration count), and
+an exported `t2v_probe_read(unsigned long long* out, int reset)` that copies / clears the symbol."""
 import sys, os, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, t2v_amd
 import t2v_amd.functional as F, t2v_amd.native as nv
