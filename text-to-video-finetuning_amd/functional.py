@@ -336,9 +336,9 @@ def _unprep_weight_grad(dwp, weight, cfg):
     return gw.to(weight.dtype).contiguous()
 
 
-# Factor-gradient launches (dU, dD) feed only the flat gradient buffer, i.e. they are off the critical path of
-# backward: they are issued on a side stream (forked after dt, joined once before the optimizer) so that they overlap the
-# latency-bound main chain.  Inside a HIP-graph capture this becomes a parallel branch of the graph.
+# Factor-gradient launches (dU, dD) feed only the flat gradient buffer, i.e. they are off the critical path of backward.  By
+# default their descriptors are queued and run in batches (further down).  With T2V_WGRAD_BATCH=0 they are per-layer launches
+# on a side stream (forked after dt, joined once before the optimizer; a parallel branch of a captured graph).
 _side = {"stream": None, "refs": [], "enabled": os.environ.get("T2V_WGRAD_STREAM", "1") != "0", "cb": False}
 
 
