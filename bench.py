@@ -201,8 +201,10 @@ def gemm_roofline(trainer, batch):
         taps_ = (geom.KH * geom.KW) if geom is not None else 1
         abytes = (kw["M"] * (kw["K"] // taps_) + kw["M"] * kw["N"] + kw["N"] * kw["K"]) * 2.0 * z
         records.append((flops, s, e, nn_kernel, abytes, inner))
-        shapes.append(((kw["M"], kw["N"], kw["K"], z, "conv" if geom is not None else "lin",
-                        "nn" if nn_kernel else "tn"), flops, s, e))
+        rc = (kw["N"] - kw["n_split"]) if kw.get("n_split", 0) > 0 else 0
+        gtag = "lin" if geom is None else f"conv{geom.KH}x{geom.KW}s{geom.sy}d{geom.tdiv}u{geom.up}"
+        shapes.append(((kw["M"], kw["N"] - rc, rc, kw["K"], z, gtag, "nn" if nn_kernel else "tn",
+                        "res" if kw.get("R") else "-"), flops, s, e, inner))
         if nn_kernel and geom is not None and geom.KH == 3 and geom.KW == 1:
             # the (3,1,1) Conv3d launches (forward + backward-data): SURVEY 8(d) bytes = x once + y once + weights once
             taps = 3
@@ -324,12 +326,16 @@ def gemm_roofline(trainer, batch):
     out["north_star"] = ns
     if os.environ.get("T2V_BENCH_SHAPE_TABLE"):      # per-problem-signature GEMM time of one step (diagnostic)
         agg = {}
-        for key, fl, s, e in shapes:
+        for key, fl, s, e, inner in shapes:
             a = agg.setdefault(key, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += s.elapsed_time(e); a[2] += fl
+            a[0] += 1; a[1] += dur(s, e, inner); a[2] += fl
+        tot = sum(a[1] for a in agg.values())
         with open(os.environ["T2V_BENCH_SHAPE_TABLE"], "w") as f:
+            f.write("# per-signature GEMM time of one step (kernel timestamps where the hook applies): (M, N, rank cols, K, batch, "
+                    "window, kernel, residual)\n")
             for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{str(key):60s} launches {n:4d}  ms {ms:8.3f}  us/launch {ms / n * 1e3:8.1f}  TF/s {fl / ms / 1e9:7.1f}\n")
+                f.write(f"{str(key):72s} launches {n:4d}  ms {ms:8.3f} ({100 * ms / tot:4.1f} %)  us/launch {ms / n * 1e3:8.1f}  "
+                        f"GFLOP {fl / n / 1e9:8.2f}  TF/s {fl / ms / 1e9:7.1f}\n")
     if kev is not None:
         kev.close()
     return out
