@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libt2v_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "lora_wgrad.hip", "lora_merge.hip"]
+SOURCES = ["gemm.hip", "gemm_w8.hip", "norm.hip", "attn.hip", "elementwise.hip", "lora_wgrad.hip", "lora_merge.hip"]
 
 
 def _digest():

@@ -86,6 +86,9 @@ inline void t2v_launch_timed(int which, F kern, dim3 grid, dim3 block, unsigned 
 #define T2V_LAUNCH_LAST(kern, grid, block, smem, stream, ...) t2v_launch_timed(2, kern, grid, block, smem, stream, __VA_ARGS__)
 
 void t2v_set_error(const char* fmt, ...);
+// gemm_w8.hip: 8-wave one-workgroup-per-CU GEMM configurations (descriptor already validated by gemm.hip)
+int t2v_gemm_w8_configs(void);
+int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, hipStream_t s);
 #define T2V_CHECK_ARG(cond, ...)          \
   do {                                    \
     if (!(cond)) {                        \

@@ -1325,6 +1325,19 @@ extern "C" int t2v_gemm_tune_import(const char* text) {
   return count;
 }
 
+// conditions of the 8-wave kernels (gemm_w8.hip): the lean loader plus the bf16 epilogue without dropout / split-K
+static bool w8_ok(const T2VGemm& p) {
+  return !p.a_trans && !p.b_trans && p.split_k <= 1 && p.batch <= 1 && p.out_mode == T2V_OUT_BF16 && p.drop_p == 0.f &&
+         (p.N & 7) == 0 && lean_ok(p);
+}
+
+extern "C" int t2v_gemm_w8(const T2VGemm* pp, int cfg, int nstep, t2v_stream_t stream) {
+  T2V_CHECK_ARG(pp != nullptr, "t2v_gemm_w8: null descriptor");
+  if (int e = check_gemm(*pp)) return e;
+  T2V_CHECK_ARG(w8_ok(*pp), "t2v_gemm_w8: descriptor outside the 8-wave kernels' domain (K%%64, C%%64, bf16 output, no dropout/batch)");
+  return t2v_gemm_w8_launch(*pp, cfg, nstep, (hipStream_t)stream);
+}
+
 extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {
   T2V_CHECK_ARG(pp != nullptr, "t2v_gemm: null descriptor");
   T2VGemm p = *pp;
