@@ -31,8 +31,8 @@ SHAPES = [
     (512, 1280, 16, 3840, 3, 0), (512, 1280, 16, 11520, 9, 0),
     (65536, 512, 0, 4608, 9, 1), (262144, 256, 0, 2304, 9, 1), (1048576, 128, 0, 1152, 9, 0),
 ]
-BN = {0: 384, 1: 384, 2: 256, 3: 192, 4: 256, 5: 256, 6: 192, 7: 384, 8: 256, 9: 384, 10: 256, 11: 192, 12: 384, 13: 128}
-BM = {0: 128, 1: 128, 2: 256, 3: 128, 4: 128, 5: 256, 6: 128, 7: 128, 8: 256, 9: 128, 10: 128, 11: 128, 12: 256, 13: 256}
+BN = {0: 384, 1: 384, 2: 256, 3: 192, 4: 256, 5: 256, 6: 384, 7: 256, 8: 384, 9: 384, 10: 128, 11: 256, 12: 384, 13: 256, 14: 192, 15: 384, 16: 256}
+BM = {0: 128, 1: 128, 2: 256, 3: 128, 4: 128, 5: 256, 6: 128, 7: 256, 8: 256, 9: 128, 10: 256, 11: 128, 12: 128, 13: 256, 14: 128, 15: 128, 16: 128}
 ONLY = [int(x) for x in os.environ["W8_ONLY"].split(",")] if os.environ.get("W8_ONLY") else None
 
 
@@ -137,6 +137,18 @@ for M, N, rc, K, taps, res in SHAPES:
             g1 = per[[i for i in range(nw) if (i % 8) >= 4]].mean(0)
             print(f"      cycles per phase pair (M work, wait at M barrier, C issue, wait at C barrier): group0 "
                   f"{[round(float(x)) for x in g0]} sum {float(g0.sum()):.0f} | group1 {[round(float(x)) for x in g1]} sum {float(g1.sum()):.0f}")
+        if int(os.environ.get("T2V_W8_DBG", "0")) & 8:      # timeline probe: per-workgroup stamps (cycles)
+            ws = F._gemm_workspace()
+            ws[: 4096 * 16].zero_()
+            lib.t2v_gemm_w8(C.byref(descs[0]), cfg, st, nv.stream())
+            torch.cuda.synchronize()
+            raw = ws[: 4096 * 16].view(torch.int64).view(4096, 8).cpu().double()
+            raw = raw[raw[:, 0] > 0]
+            t00 = raw[:, 0].min()
+            rel = raw[:, :5] - t00
+            names = ["entry", "setup done", "first stage landed", "K loop done", "stores done"]
+            print("      timeline (cycles after the first workgroup's entry; mean / max over workgroups): "
+                  + "; ".join(f"{n} {float(rel[:, i].mean()):.0f}/{float(rel[:, i].max()):.0f}" for i, n in enumerate(names)))
         flag = "" if err < 2e-2 else "   <-- MISMATCH"
         print(f"    cfg {cfg} ({BM[cfg]}x{BN[cfg]}) step {st:3d} wgs {wgs:4d}: {us:7.1f} us {fl / us / 1e6:7.1f} TF/s  x{base / us:4.2f}  err {err:.1e}{flag}",
               flush=True)
