@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 1
+#define T2V_ABI_VERSION 2   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -97,8 +97,9 @@ typedef struct {
    * the row itself: `dt = dy U` inside the backward-data launch of a stride-1 conv.  b2_klen <= 0: B2 rows span all of K. */
   int b2_k0, b2_klen;
   /* optional caller-owned fp32 scratch (>= M*N*4 bytes): lets the library split K across workgroups for deep-K launches
-   * with few output tiles (partials are accumulated in the scratch, a finalize pass applies the epilogue).
-   * ws_split is internal (set 0). */
+   * with few output tiles (partials are accumulated in the scratch, a finalize pass applies the epilogue; the 8-wave kernels
+   * reduce inside the launch and keep arrival counters in the first 64 KB, which must be ZERO when the scratch is first handed
+   * over and are left zero by every launch).  ws_split is internal (set 0). */
   void* workspace; size_t workspace_bytes; int ws_split;
   /* internal (set 0): tile rasterisation chosen by the library — 0: an XCD owns a run of M-tiles x all N-tiles (activation
    * panels stay in its L2, every XCD streams the whole weight matrix); 1: an XCD owns a run of N-tiles x all M-tiles (each
@@ -108,6 +109,14 @@ typedef struct {
   const unsigned long long* drop_epoch;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
+/* Pinned launch on one of the 8-wave, one-workgroup-per-CU configurations of csrc/gemm_w8.hip (what t2v_gemm selects through
+ * the tile table for lean descriptors: K%64==0, window C%64==0, bf16 output, no dropout / batch); for tuning runs, the
+ * configuration probes (scripts/w8_probe.py) and the kernel tests.  cfg: configuration index (t2v_gemm_w8_configs() of them);
+ * nstep: column step of the tile grid (multiple of 32, <= the configuration's BN; 0 = BN); splits: K splits reduced inside the
+ * launch through `workspace` (first 64 KB = arrival counters, zero when the scratch is first handed over; the kernels leave
+ * them zero) — clamped to what K and the scratch admit. */
+int t2v_gemm_w8(const T2VGemm* p, int cfg, int nstep, int splits, t2v_stream_t stream);
+int t2v_gemm_w8_configs(void);
 /* Dropout epoch.  Every dropout-capable entry point (t2v_gemm epilogue, t2v_gn_apply / t2v_gn_bwd_*, t2v_lowrank_update_drop,
  * t2v_dropout_mask) takes its seed BY VALUE, so a captured HIP graph would replay the same masks every step.  With an epoch
  * registered, the launches issued afterwards also carry the ADDRESS of this 8-byte device counter and use

@@ -76,6 +76,18 @@ int main() {
       {"rows pitch 1024 B, private 128 KB, 256 WGs", 256, 128 << 10, 128u << 10, 1024, 2},
       {"rows pitch 5760 B (weights K=2880), shared 1.9 MB, 256 WGs", 256, 0, 336u * 5760u, 5760, 2},
       {"rows pitch 640 B, private 80 KB, 64 WGs", 64, 80 << 10, 80u << 10, 640, 2},
+      // row-pitch sweep, L2-resident and too big for the 32 KB L1s: every workgroup walks the SAME 2048-row panel (first 128 B
+      // of each row = one K slice), 8 rows per wave-instruction — do power-of-two-ish pitches pile the rows onto few L2 channels?
+      {"panel 2048 rows, pitch  640 B (C=320)", 256, 0, 2048u * 640u, 640, 2},
+      {"panel 2048 rows, pitch 1280 B (C=640)", 256, 0, 2048u * 1280u, 1280, 2},
+      {"panel 2048 rows, pitch 2560 B (C=1280)", 256, 0, 2048u * 2560u, 2560, 2},
+      {"panel 2048 rows, pitch 2688 B (C=1280 + 64 pad)", 256, 0, 2048u * 2688u, 2688, 2},
+      {"panel 2048 rows, pitch 1024 B (C=512)", 256, 0, 2048u * 1024u, 1024, 2},
+      {"panel 2048 rows, pitch 1152 B (C=512 + 64 pad)", 256, 0, 2048u * 1152u, 1152, 2},
+      {"panel 1296 rows, pitch 23040 B (weights K=11520)", 256, 0, 1296u * 23040u, 23040, 2},
+      {"panel 1296 rows, pitch 23168 B (K=11520 + 64 pad)", 256, 0, 1296u * 23168u, 23168, 2},
+      {"panel 1296 rows, pitch 20480 B (weights K=10240)", 256, 0, 1296u * 20480u, 20480, 2},
+      {"panel 1296 rows, pitch 20608 B (K=10240 + 64 pad)", 256, 0, 1296u * 20608u, 20608, 2},
   };
   for (const Case& c : cases) {
     for (int depth : {4, 16}) {

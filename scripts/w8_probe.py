@@ -17,8 +17,6 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 dev, bf = "cuda", torch.bfloat16
 lib = nv.lib()
-lib.t2v_gemm_w8.argtypes = [C.POINTER(nv.Gemm), C.c_int, C.c_int, C.c_void_p]
-lib.t2v_gemm_w8.restype = C.c_int
 
 # (M, N, rank columns, K, taps, residual)
 SHAPES = [
@@ -31,14 +29,14 @@ SHAPES = [
     (512, 1280, 16, 3840, 3, 0), (512, 1280, 16, 11520, 9, 0),
     (65536, 512, 0, 4608, 9, 1), (262144, 256, 0, 2304, 9, 1), (1048576, 128, 0, 1152, 9, 0),
 ]
-BN = {0: 384, 1: 384, 2: 256, 3: 192, 4: 256, 5: 256, 6: 384, 7: 256, 8: 384, 9: 384, 10: 128, 11: 256, 12: 384, 13: 256, 14: 192, 15: 384, 16: 256}
-BM = {0: 128, 1: 128, 2: 256, 3: 128, 4: 128, 5: 256, 6: 128, 7: 256, 8: 256, 9: 128, 10: 256, 11: 128, 12: 128, 13: 256, 14: 128, 15: 128, 16: 128}
+BN = {0: 384, 1: 384, 2: 256, 3: 192, 4: 256, 5: 256, 6: 384, 7: 256, 8: 384, 9: 384, 10: 128, 11: 256, 12: 384, 13: 256, 14: 192, 15: 384, 16: 256, 17: 384, 18: 256, 19: 192, 20: 256}
+BM = {0: 128, 1: 128, 2: 256, 3: 128, 4: 128, 5: 256, 6: 128, 7: 256, 8: 256, 9: 128, 10: 256, 11: 128, 12: 128, 13: 256, 14: 128, 15: 128, 16: 128, 17: 128, 18: 256, 19: 128, 20: 128}
 ONLY = [int(x) for x in os.environ["W8_ONLY"].split(",")] if os.environ.get("W8_ONLY") else None
 
 
-def candidates(M, Ntot):
+def candidates(M, Ntot, K):
     if os.environ.get("W8_CFGS"):                     # "cfg:step,cfg:step": pinned candidates (ablation runs)
-        return [(int(a), int(b), 0) for a, b in (x.split(":") for x in os.environ["W8_CFGS"].split(","))]
+        return [(int(x.split(":")[0]), int(x.split(":")[1]), 0, int((x.split(":") + ["1"])[2])) for x in os.environ["W8_CFGS"].split(",")]
     out = []
     for cfg in sorted(BN):
         if ONLY is not None and cfg not in ONLY:
@@ -58,9 +56,12 @@ def candidates(M, Ntot):
             while (ntn - 1) * st + bn < Ntot:
                 ntn += 1
             wgs = -(-M // BM[cfg]) * ntn
-            if wgs < 48:
-                continue
-            out.append((cfg, st, wgs))
+            for sp in (1, 2, 3, 4, 6, 8):
+                if sp > 1 and (wgs * sp > 320 or K // 64 // sp < 4):
+                    continue
+                if wgs * sp < 48:
+                    continue
+                out.append((cfg, st, wgs * sp, sp))
     return out
 
 
@@ -114,11 +115,11 @@ for M, N, rc, K, taps, res in SHAPES:
     scale = float(ref.abs().max())
     print(f"{tag}: table kernel {base:7.1f} us {fl / base / 1e6:7.1f} TF/s", flush=True)
     best = (base, "table")
-    for cfg, st, wgs in candidates(M, N + rc):
+    for cfg, st, wgs, sp in candidates(M, N + rc, K):
         Ds[0].zero_()
         if rc:
             keep[0][1].zero_()
-        rcode = lib.t2v_gemm_w8(C.byref(descs[0]), cfg, st, nv.stream())
+        rcode = lib.t2v_gemm_w8(C.byref(descs[0]), cfg, st, sp, nv.stream())
         if rcode != 0:
             print(f"    cfg {cfg} step {st}: rc={rcode} {lib.t2v_last_error().decode()}")
             continue
@@ -126,7 +127,7 @@ for M, N, rc, K, taps, res in SHAPES:
         err = float((Ds[0].float() - ref).abs().max()) / scale
         if rc:
             err = max(err, float((keep[0][1].float() - reft).abs().max()) / max(1e-9, float(reft.abs().max())))
-        us = timeit(lambda i: lib.t2v_gemm_w8(C.byref(descs[i & 1]), cfg, st, nv.stream()))
+        us = timeit(lambda i: lib.t2v_gemm_w8(C.byref(descs[i & 1]), cfg, st, sp, nv.stream()))
         if int(os.environ.get("T2V_W8_DBG", "0")) & 4:      # phase-cycle probe of the ping-pong schedule (per-wave totals)
             ws = F._gemm_workspace()
             nw = min(wgs if wgs else 256, 256) * 8
@@ -139,10 +140,10 @@ for M, N, rc, K, taps, res in SHAPES:
                   f"{[round(float(x)) for x in g0]} sum {float(g0.sum()):.0f} | group1 {[round(float(x)) for x in g1]} sum {float(g1.sum()):.0f}")
         if int(os.environ.get("T2V_W8_DBG", "0")) & 8:      # timeline probe: per-workgroup stamps (cycles)
             ws = F._gemm_workspace()
-            ws[: 4096 * 16].zero_()
-            lib.t2v_gemm_w8(C.byref(descs[0]), cfg, st, nv.stream())
+            ws[16384: 16384 + 4096 * 16].zero_()
+            lib.t2v_gemm_w8(C.byref(descs[0]), cfg, st, sp, nv.stream())
             torch.cuda.synchronize()
-            raw = ws[: 4096 * 16].view(torch.int64).view(4096, 8).cpu().double()
+            raw = ws[16384: 16384 + 4096 * 16].view(torch.int64).view(4096, 8).cpu().double()
             raw = raw[raw[:, 0] > 0]
             t00 = raw[:, 0].min()
             rel = raw[:, :5] - t00
@@ -150,9 +151,9 @@ for M, N, rc, K, taps, res in SHAPES:
             print("      timeline (cycles after the first workgroup's entry; mean / max over workgroups): "
                   + "; ".join(f"{n} {float(rel[:, i].mean()):.0f}/{float(rel[:, i].max()):.0f}" for i, n in enumerate(names)))
         flag = "" if err < 2e-2 else "   <-- MISMATCH"
-        print(f"    cfg {cfg} ({BM[cfg]}x{BN[cfg]}) step {st:3d} wgs {wgs:4d}: {us:7.1f} us {fl / us / 1e6:7.1f} TF/s  x{base / us:4.2f}  err {err:.1e}{flag}",
+        print(f"    cfg {cfg} ({BM[cfg]}x{BN[cfg]}) step {st:3d} split {sp} wgs {wgs:4d}: {us:7.1f} us {fl / us / 1e6:7.1f} TF/s  x{base / us:4.2f}  err {err:.1e}{flag}",
               flush=True)
         if err < 2e-2 and us < best[0]:
-            best = (us, f"cfg {cfg} step {st}")
+            best = (us, f"cfg {cfg} step {st} split {sp}")
     print(f"  -> best {best[1]}: {best[0]:.1f} us {fl / best[0] / 1e6:.1f} TF/s (x{base / best[0]:.2f} vs table)", flush=True)
     del As, Ds, Rs

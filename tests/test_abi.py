@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = ctypes.CDLL(nv.LIB_PATH)
     for name in _declared():
         assert hasattr(lib, name), name
-    assert nv.lib().t2v_abi_version() == 1
+    assert nv.lib().t2v_abi_version() == nv.ABI_VERSION
 
 
 def test_ctypes_structs_mirror_header_sizes():

@@ -964,13 +964,26 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const T2VGemm p, int
 
 // pick the tile that minimises (waves of workgroups) x (tile cost); ~2 workgroups resident per CU
 // ---- NN (LDS-DMA) launch configurations: tile x ring depth x workspace split-K -------------------------------------
+// conditions of the 8-wave kernels (gemm_w8.hip): the lean loader plus the bf16 epilogue without dropout / split-K
+bool w8_ok(const T2VGemm& p) {
+  return !p.a_trans && !p.b_trans && p.split_k <= 1 && p.batch <= 1 && p.out_mode == T2V_OUT_BF16 && p.drop_p == 0.f &&
+         (p.N & 7) == 0 && lean_ok(p);
+}
+
+constexpr int W8_BASE = 100;   // DmaCfg.tile >= W8_BASE: 8-wave configuration tile - W8_BASE, stages = column step / 32 (0 = BN), split = K splits
 struct DmaCfg {
   int tile;    // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32, 4: 256x128, 5: 128x320, 6: 256x320, 7: 256x256, 8: 128x256 (4-7: 8 waves)
   int stages;  // 2 = occupancy variant, 0 = deep ring (3 for 128x128, 4 otherwise)
   int split;   // 1 = none, >1 = split K through the fp32 workspace + finalize pass
 };
 
+DmaCfg heuristic_cfg(const T2VGemm& p);
+
 int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
+  if (c.tile >= W8_BASE) {
+    if (w8_ok(p)) return t2v_gemm_w8_launch(p, c.tile - W8_BASE, c.stages * 32, c.split, s);
+    return launch_dma_cfg(p, heuristic_cfg(p), s);     // (a table entry met a descriptor outside the 8-wave domain)
+  }
   T2VGemm q = p;
   int split = c.split;
   // a cached / pinned configuration may ask for split-K while THIS launch brings no (or too small a) scratch buffer
@@ -1087,7 +1100,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   if (!g_autotune) return heuristic_cfg(p);
   if (const char* f = getenv("T2V_GEMM_FORCE_CFG")) {       // "tile,stages,split": pin one configuration (counter passes, A/B runs)
     int t = 0, st = 2, sp = 1;
-    if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && t >= 0 && t <= 9) return DmaCfg{t, st, sp < 1 ? 1 : sp};
+    if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && ((t >= 0 && t <= 9) || t >= W8_BASE)) return DmaCfg{t, st, sp < 1 ? 1 : sp};
   }
   const TuneKey key = make_key(p);
   {
@@ -1124,6 +1137,42 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
           if (p.K / sp < 256 || tiles * sp > 2048) continue;
           if ((size_t)p.M * p.N * 4 * sp + 16 > p.workspace_bytes) continue;
           cand.push_back(DmaCfg{t, st, sp});
+        }
+      }
+    }
+  }
+  if (w8_ok(p) && !getenv("T2V_GEMM_NO_W8")) {
+    // 8-wave one-workgroup-per-CU configurations (gemm_w8.hip): tile BM x BN of the production set, column steps that split N
+    // evenly into whole fragments (or 160 / 320 = half / whole level-0 width), K splits that bring the launch to about one
+    // round of workgroups
+    static const int W8[][3] = {{12, 128, 384}, {17, 128, 384}, {13, 256, 256}, {18, 256, 256}, {14, 128, 192}, {19, 128, 192},
+                                {16, 128, 256}, {20, 128, 256}};
+    for (const auto& w : W8) {
+      const int bm = w[1], bn = w[2];
+      if (p.M < bm / 2) continue;
+      int steps[4], nsteps = 0;
+      auto add = [&](int st) {
+        if (st <= 0 || st > bn) return;
+        for (int i = 0; i < nsteps; ++i)
+          if (steps[i] == st) return;
+        steps[nsteps++] = st;
+      };
+      add(bn);
+      for (int ntn = 1; ntn < 64; ++ntn) {
+        const int st = ((p.N + ntn - 1) / ntn + 31) / 32 * 32;
+        if (st <= bn) { add(st); break; }
+      }
+      if (p.N > 160) add(160);
+      if (p.N > 320) add(320);
+      for (int i = 0; i < nsteps; ++i) {
+        const int st = steps[i];
+        int ntn = 1;
+        while ((long long)(ntn - 1) * st + bn < p.N) ++ntn;
+        const long long wgs = (long long)((p.M + bm - 1) / bm) * ntn;
+        for (int sp : {1, 2, 3, 4, 6, 8}) {
+          if (sp > 1 && (wgs * sp > 320 || p.K / 64 / sp < 4 || !p.workspace)) continue;
+          if (wgs * sp < 40) continue;
+          cand.push_back(DmaCfg{W8_BASE + w[0], st / 32, sp});
         }
       }
     }
@@ -1313,7 +1362,9 @@ extern "C" int t2v_gemm_tune_import(const char* text) {
     int consumed = 0;
     if (sscanf(p, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d%n", &k.M, &k.N, &k.K, &k.a_mode, &k.n_split, &k.out_mode,
                &k.has_res, &k.batch, &k.KH, &k.KW, &k.sy, &k.tdiv, &k.up, &k.C, &c.tile, &c.stages, &c.split, &consumed) == 17) {
-      if (c.tile >= 0 && c.tile <= 9 && (c.stages == 0 || c.stages == 2) && c.split >= 1 && c.split <= 64) {
+      const bool w8 = c.tile >= W8_BASE && c.tile < W8_BASE + t2v_gemm_w8_configs() && c.stages >= 0 && c.stages <= 12 && c.split >= 1 &&
+                      c.split <= 8;
+      if (w8 || (c.tile >= 0 && c.tile <= 9 && (c.stages == 0 || c.stages == 2) && c.split >= 1 && c.split <= 64)) {
         g_tuned[k] = c;
         ++count;
       }
@@ -1325,17 +1376,11 @@ extern "C" int t2v_gemm_tune_import(const char* text) {
   return count;
 }
 
-// conditions of the 8-wave kernels (gemm_w8.hip): the lean loader plus the bf16 epilogue without dropout / split-K
-static bool w8_ok(const T2VGemm& p) {
-  return !p.a_trans && !p.b_trans && p.split_k <= 1 && p.batch <= 1 && p.out_mode == T2V_OUT_BF16 && p.drop_p == 0.f &&
-         (p.N & 7) == 0 && lean_ok(p);
-}
-
-extern "C" int t2v_gemm_w8(const T2VGemm* pp, int cfg, int nstep, t2v_stream_t stream) {
+extern "C" int t2v_gemm_w8(const T2VGemm* pp, int cfg, int nstep, int splits, t2v_stream_t stream) {
   T2V_CHECK_ARG(pp != nullptr, "t2v_gemm_w8: null descriptor");
   if (int e = check_gemm(*pp)) return e;
   T2V_CHECK_ARG(w8_ok(*pp), "t2v_gemm_w8: descriptor outside the 8-wave kernels' domain (K%%64, C%%64, bf16 output, no dropout/batch)");
-  return t2v_gemm_w8_launch(*pp, cfg, nstep, (hipStream_t)stream);
+  return t2v_gemm_w8_launch(*pp, cfg, nstep, splits, (hipStream_t)stream);
 }
 
 extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {

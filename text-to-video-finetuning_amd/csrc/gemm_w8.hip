@@ -45,7 +45,7 @@ __device__ __forceinline__ void wait_vmcnt_sel(bool first) {
 }
 
 template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT>
-__global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int nstep, const int ntn, const int dbg) {
+__global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int nstep, const int ntn, const int splits, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(WM * WN * KG == 8 && (KG == 1 || KG == 2), "eight waves: WM x WN x KG");
   static_assert(BKT == 64 || BKT == 32, "stage depth");
@@ -59,6 +59,9 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   constexpr int NCA = BM / RPP, NCB = BN / RPP, LPT = NCA + NCB;
   constexpr int WROWS = 64 / CPW;                  // rows one wave covers in a pass
   static_assert(BM % RPP == 0 && BN % RPP == 0 && TM % 32 == 0 && TN % 32 == 0, "tile/wave mismatch");
+  constexpr int RING_BYTES = NSTAGE * STAGE;
+  constexpr int EPI_BYTES = (WM * 32 * BN * 4 > 128 * 1024 ? WM / 2 : WM) * 32 * BN * 4;
+  constexpr int SMEM_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;      // + 16 bytes for the split-K ticket word
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long tl[5] = {0, 0, 0, 0, 0};      // timeline probe (T2V_W8_DBG=8)
@@ -67,13 +70,31 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   const int wr = wave % WM, kg = (wave / WM) % KG, wc = wave / (WM * KG);
   const int M = p.M, N = p.N;
   const T2VConvGeom g = p.geom;
-  const int ntiles = gridDim.x;
+  // grid = output tiles x K splits (split index slowest: the splits of a tile sit ntiles apart, on the same XCD when
+  // ntiles % 8 == 0); split z owns the K steps [z*nt_all/S, (z+1)*nt_all/S)
+  const int ntiles = gridDim.x / splits;
+  const int bz = blockIdx.x / ntiles, bt = blockIdx.x - bz * ntiles;
   int t;
   {
-    int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    int q = ntiles >> 3, r = ntiles & 7, xcd = bt & 7, idx = bt >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = t / ntn, tn = t - tm * ntn;
+  const int nt_all = p.K / BKT;
+  const int ks0 = (int)((long long)bz * nt_all / splits), ks1 = (int)((long long)(bz + 1) * nt_all / splits);
+  const int nt = ks1 - ks0, kbeg = ks0 * BKT;
+  // raster_n & 1: an XCD's contiguous run of tiles covers a few N-tiles x ALL M-tiles (each weight column block is pulled
+  // into ONE L2; the activations are streamed by every XCD) instead of a few M-tiles x all N-tiles.  What misses the L2s is
+  // served at ~6 TB/s against 30+ TB/s for hits (profiles/r03_dma_bw_probe.txt), so the launcher picks the order that
+  // re-streams the SMALLER operand eight times.
+  int tm, tn;
+  if (p.raster_n & 1) {
+    const int ntm = ntiles / ntn;
+    tn = t / ntm;
+    tm = t - tn * ntm;
+  } else {
+    tm = t / ntn;
+    tn = t - tm * ntn;
+  }
   const long long m0 = (long long)tm * BM;
   const int n0 = tn * nstep;
   const int ncols = min(N - n0, tn == ntn - 1 ? BN : nstep);        // columns this tile owns (multiple of 8)
@@ -106,6 +127,12 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     }
   }
   int sc = 0, sky = 0, skx = 0;                    // scalar window position of the NEXT stage: channel, tap row / col
+  if (is_conv && kbeg > 0) {
+    const int tap0 = kbeg / g.C;
+    sc = kbeg - tap0 * g.C;
+    sky = tap0 / g.KW;
+    skx = tap0 - sky * g.KW;
+  }
   auto conv_rows = [&]() {
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
@@ -150,7 +177,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   // pieces [lo, hi) of the LPT per-thread LDS-DMA loads of one stage (A passes first); the phased schedules spread a stage
   // over several phases.  advance_window() after the stage's last A piece.
   auto issue_pieces = [&](int k0, int stage, int lo, int hi) {
-    if ((dbg & 1) && k0 >= NSTAGE * BKT) return;     // ablation (T2V_W8_DBG=1): steady state without operand traffic
+    if ((dbg & 1) && k0 >= kbeg + NSTAGE * BKT) return;     // ablation (T2V_W8_DBG=1): steady state without operand traffic
     unsigned char* sA = smem + stage * STAGE;
     unsigned char* sB = sA + A_BYTES;
     const int soa = (is_conv ? sc : k0) * 2;
@@ -205,7 +232,6 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   const unsigned brow = (unsigned)(wc * TN + (lane & 31)) * (unsigned)ROWB;
   // column fragments of this wave that hold columns of the tile
   const int nfw = max(0, min(FN, (ncols - wc * TN + 31) >> 5));
-  const int nt = p.K / BKT;
 
   if (dbg & 8) tl[1] = __builtin_readcyclecounter();
   auto kloop = [&](auto nf_tag) {
@@ -245,7 +271,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       constexpr int PP = (LPT + NPH - 1) / NPH;
 #pragma unroll
       for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nt) issue(s * BKT, s);
+        if (s < nt) issue(kbeg + s * BKT, s);
       int stage = 0;
       for (int it = 0; it < nt; ++it) {
         const int ahead = min(nt, it + NSTAGE - 1) - (it + 1);
@@ -257,11 +283,11 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         const bool refill = it + NSTAGE - 1 < nt;
         int ws = stage + NSTAGE - 1;
         if (ws >= NSTAGE) ws -= NSTAGE;
-        if (SCHED == 0 && refill) issue((it + NSTAGE - 1) * BKT, ws);
+        if (SCHED == 0 && refill) issue(kbeg + (it + NSTAGE - 1) * BKT, ws);
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
           if (SCHED == 4 && refill && j < NPH) {
-            issue_pieces((it + NSTAGE - 1) * BKT, ws, j * PP, (j + 1) * PP < LPT ? (j + 1) * PP : LPT);
+            issue_pieces(kbeg + (it + NSTAGE - 1) * BKT, ws, j * PP, (j + 1) * PP < LPT ? (j + 1) * PP : LPT);
             if (j == NPH - 1) advance_window();
           }
           bf16x8 af[FM], bfr[FN];
@@ -269,6 +295,64 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           mfma(af, bfr);
         }
         if (++stage == NSTAGE) stage = 0;
+      }
+    } else if constexpr (SCHED == 5) {
+      // classic ring, software-pipelined: the fragments of k16 step j+1 are read (second register set) before step j multiplies;
+      // the per-stage wait + barrier sits BEFORE the last k16 step, so the hand-over and the first fragment reads of the next
+      // stage run under that step's MFMAs; the refill of the slot freed by the barrier goes out in three portions (behind the
+      // barrier, and in the first two k16 steps of the next stage) instead of one burst.
+      static_assert(KS % 2 == 0, "two fragment sets alternate per k16 step");
+      constexpr int NP = KS >= 4 ? 3 : 2;                   // portions of a refill
+      constexpr int PP = (LPT + NP - 1) / NP;
+#pragma unroll
+      for (int s = 0; s < NSTAGE; ++s)
+        if (s < nt) issue(kbeg + s * BKT, s);
+      {
+        const int ahead = min(nt, NSTAGE) - 1;
+        if (ahead >= 2) wait_vmcnt<2 * LPT>();
+        else if (ahead == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (dbg & 8) tl[2] = __builtin_readcyclecounter();
+      bf16x8 af0[FM], bf0[FN], af1[FM], bf1[FN];
+      load_frags(af0, bf0, 0, kg * KS);
+      int stage = 0, pk = 0, pslot = 0;
+      bool pend = false;                                    // a refill whose later portions are still to go out
+      for (int it = 0; it < nt; ++it) {
+        // k16 steps 0 .. KS-2 (pairs: set0 then set1)
+#pragma unroll
+        for (int j = 0; j + 1 < KS; ++j) {
+          if (j & 1) load_frags(af0, bf0, stage, kg * KS + j + 1);
+          else load_frags(af1, bf1, stage, kg * KS + j + 1);
+          if (pend && j + 1 < NP) {
+            issue_pieces(pk, pslot, (j + 1) * PP, (j + 2) * PP < LPT ? (j + 2) * PP : LPT);
+            if (j + 2 == NP) {
+              advance_window();
+              pend = false;
+            }
+          }
+          if (j & 1) mfma(af1, bf1);
+          else mfma(af0, bf0);
+        }
+        int nstage = stage + 1;
+        if (nstage == NSTAGE) nstage = 0;
+        if (it + 1 < nt) {
+          wait_lgkm0();                                     // this wave is done reading `stage`
+          // stage it+1 landed; what may stay in flight: the stages behind it (NSTAGE = 3: stage it+2)
+          if (NSTAGE >= 3 && it + 2 < nt) wait_vmcnt<LPT>();
+          else wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();                     // stage it+1 visible to every wave; `stage` is free
+          if (it + NSTAGE < nt) {
+            pk = kbeg + (it + NSTAGE) * BKT;
+            pslot = stage;
+            issue_pieces(pk, pslot, 0, PP);
+            pend = true;
+          }
+          load_frags(af0, bf0, nstage, kg * KS);
+        }
+        mfma(af1, bf1);                                     // last k16 step of the stage (KS even: it sits in set 1)
+        stage = nstage;
       }
     } else if constexpr (SCHED == 2) {
       // ping-pong, one fragment set (read in M, consumed in C).  Phase k of group 0 runs beside phase k-1 of group 1 (group 1
@@ -281,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       const int grp = wave >> 2;
 #pragma unroll
       for (int s = 0; s < NSTAGE; ++s)
-        if (s < nt) issue(s * BKT, s);
+        if (s < nt) issue(kbeg + s * BKT, s);
       {
         const int ahead = min(nt, NSTAGE) - 1;
         if (ahead >= 2) wait_vmcnt<2 * LPT>();
@@ -307,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           // ---- M phase
           load_frags(af, bfr, stage, kg * KS + j);
           if (j < NPH && refill) {
-            issue_pieces(rs * BKT, rslot, j * PP, (j + 1) * PP < LPT ? (j + 1) * PP : LPT);
+            issue_pieces(kbeg + rs * BKT, rslot, j * PP, (j + 1) * PP < LPT ? (j + 1) * PP : LPT);
             if (j == NPH - 1) advance_window();
           }
           wait_lgkm0();
@@ -338,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       const int grp = wave >> 2;
 #pragma unroll
       for (int s = 0; s < NSTAGE; ++s)
-        if (s < nt) issue(s * BKT, s);
+        if (s < nt) issue(kbeg + s * BKT, s);
       {
         const int ahead = min(nt, NSTAGE) - 1;
         if (ahead >= 3) wait_vmcnt<3 * LPT>();
@@ -361,7 +445,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         int nstage = stage + 1;
         if (nstage == NSTAGE) nstage = 0;
         // ---- M(it, 0)
-        if (refill) issue_pieces(rs * BKT, rslot, 0, PP);
+        if (refill) issue_pieces(kbeg + rs * BKT, rslot, 0, PP);
         wait_lgkm0();
         phase_barrier();
         // ---- C(it, 0)
@@ -376,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         phase_barrier();
         // ---- M(it, 1)
         if (refill) {
-          issue_pieces(rs * BKT, rslot, PP, LPT);
+          issue_pieces(kbeg + rs * BKT, rslot, PP, LPT);
           advance_window();
         }
         wait_lgkm0();
@@ -445,6 +529,43 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       }
     }
   }
+  // ---- split-K hand-off (splits > 1).  The splits of a tile draw a ticket when their K loop is done; the LAST one keeps its
+  // partial tile in LDS / registers and becomes the reducer, the others write theirs as fp32 rows to the caller's workspace
+  // (slab [tile][z]) and then count themselves done.  The reducer waits for splits-1 done marks (those workgroups finished
+  // their K loops BEFORE it did, so they are resident and running: no co-residency assumption), acquires, and adds the slabs
+  // IN SPLIT ORDER with its own partial in its place — the sum does not depend on who came last.
+  // Guide G16 forms: writers = plain stores -> every wave vmcnt(0) -> barrier -> lane 0 agent release -> counter;
+  // reducer = relaxed polls -> one agent acquire -> barrier -> plain loads.
+  int role = 0;                                    // 0: no split, 1: writer, 2: reducer
+  unsigned* cnt = nullptr;
+  float* slab0 = nullptr;                          // slab of (tile, z = 0); slab z at + z * BM*BN floats
+  if (splits > 1) {
+    cnt = (unsigned*)p.workspace + 2 * (tm * ntn + tn);
+    slab0 = (float*)((unsigned char*)p.workspace + 65536) + (long long)(tm * ntn + tn) * splits * (BM * BN);
+    int* flag = (int*)(smem + SMEM_BYTES);         // 16 spare bytes behind the ring / staging buffer (same LDS object)
+    if (tid == 0) *flag = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(*flag);
+    role = ticket == splits - 1 ? 2 : 1;
+    if (role == 2) {
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(splits - 1)) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 24)) {               // give up instead of hanging the device; flagged for the host
+            ((unsigned*)p.workspace)[16383] = 0xdeadu;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // re-armed for the next launch
+        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
+  }
+  const bool writer = role == 1;
+  if (writer) R = nullptr;
 #pragma unroll
   for (int ps = 0; ps < FM * WRP; ++ps) {
     const int i = ps / WRP, h = ps % WRP;
@@ -497,6 +618,32 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           const float4 b = *(const float4*)(sC + rl * BN + cc * 8 + 4);
           v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         }
+        if (role != 0) {
+          // row of the tile in the slabs: (wave row band, fragment band i, row in band) -> tile row
+          const int trow = (h * WPP + (rl >> 5)) * TM + i * 32 + (rl & 31);
+          float* sp = slab0 + (long long)trow * BN + cc * 8;
+          if (writer) {
+            float* wp = sp + (long long)bz * (BM * BN);
+            *(float4*)wp = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            continue;
+          }
+          float tot[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tot[e] = 0.f;
+          for (int z = 0; z < splits; ++z) {           // fixed order; this workgroup's partial takes its own place
+            if (z == bz) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) tot[e] += v[e];
+            } else {
+              const float4 a = *(const float4*)(sp + (long long)z * (BM * BN));
+              const float4 b = *(const float4*)(sp + (long long)z * (BM * BN) + 4);
+              tot[0] += a.x; tot[1] += a.y; tot[2] += a.z; tot[3] += a.w; tot[4] += b.x; tot[5] += b.y; tot[6] += b.z; tot[7] += b.w;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = tot[e];
+        }
         if (alpha != 1.f) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= alpha;
@@ -524,19 +671,28 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       }
     }
   }
-  if ((dbg & 8) && p.workspace && tid == 0) {
+  if (writer) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's slab rows have left
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the compiler may drop the fence's own wait, guide G16)
+      __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if ((dbg & 8) && p.workspace && tid == 0 && splits == 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the stores of this wave have left
     tl[4] = __builtin_readcyclecounter();
-    unsigned long long* o = (unsigned long long*)p.workspace + (long long)blockIdx.x * 8;
+    unsigned long long* o = (unsigned long long*)((unsigned char*)p.workspace + 65536) + (long long)blockIdx.x * 8;   // (behind the split-K counters)
     for (int q = 0; q < 5; ++q) o[q] = tl[q];
   }
 }
 
 template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT>
-int launch_w8(const T2VGemm& p, int nstep, hipStream_t s) {
+int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BKT * 2;
   constexpr int EPI = (WM * 32 * BN * 4 > 128 * 1024 ? WM / 2 : WM) * 32 * BN * 4;
-  constexpr int SMEM = RING > EPI ? RING : EPI;
+  constexpr int SMEM = (RING > EPI ? RING : EPI) + 16;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   T2V_CHECK_ARG(p.n_split <= 0 || p.n_split % (64 / (BKT / 8)) == 0,
                 "t2v_gemm_w8: n_split=%d must be a multiple of %d for this configuration", p.n_split, 64 / (BKT / 8));
@@ -552,8 +708,22 @@ int launch_w8(const T2VGemm& p, int nstep, hipStream_t s) {
   const int ntm = (p.M + BM - 1) / BM;
   int ntn = 1;
   while ((long long)(ntn - 1) * nstep + BN < p.N) ++ntn;      // the last tile takes up to BN columns
+  // K splits: every split gets at least NSTAGE stages; the slabs + counters must fit the caller's scratch (first 64 KB =
+  // counters, zero when the scratch is first handed over; the kernels leave them zero)
+  const int nt_all = p.K / BKT;
+  if (splits < 1) splits = 1;
+  while (splits > 1 && (nt_all / splits < NSTAGE || !p.workspace || (long long)ntm * ntn > 8000 ||
+                        65536ll + (long long)ntm * ntn * splits * BM * BN * 4 > (long long)p.workspace_bytes))
+    --splits;
   static const int dbg = [] { const char* e = getenv("T2V_W8_DBG"); return e ? atoi(e) : 0; }();
-  T2V_LAUNCH(kern, dim3(ntm * ntn), dim3(512), SMEM, s, p, nstep, ntn, dbg);
+  static const int force_raster = [] { const char* e = getenv("T2V_W8_RASTER"); return e ? atoi(e) : -1; }();   // A/B switch
+  T2VGemm q = p;
+  {
+    const double bytesA = (double)p.M * (p.a_mode == T2V_A_CONV ? p.geom.C : p.K) * 2.0;      // unique activation bytes
+    const double bytesB = (double)p.N * p.K * 2.0;
+    q.raster_n = force_raster >= 0 ? force_raster : (bytesB + 8.0 * bytesA < bytesA + 8.0 * bytesB ? 1 : 0);
+  }
+  T2V_LAUNCH(kern, dim3(ntm * ntn * splits), dim3(512), SMEM, s, q, nstep, ntn, splits, dbg);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -562,30 +732,35 @@ int launch_w8(const T2VGemm& p, int nstep, hipStream_t s) {
 
 // Number of W8 configurations and a pinned-configuration launch (tile table / tuning / diagnostics).  The caller (gemm.hip)
 // has already validated the descriptor and checked that the lean loader and the bf16 epilogue apply.
-int t2v_gemm_w8_configs(void) { return 17; }
-int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, hipStream_t s) {
+extern "C" int t2v_gemm_w8_configs(void) { return 21; }
+int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStream_t s) {
   switch (cfg) {
     //                       BM   BN  WM WN KG NS SCHED BK
-    case 0: return launch_w8<128, 384, 2, 2, 2, 2, 0, 64>(p, nstep, s);      // wave 64x192, K groups, classic ring
-    case 1: return launch_w8<128, 384, 4, 2, 1, 2, 0, 64>(p, nstep, s);      // wave 32x192
-    case 2: return launch_w8<256, 256, 4, 2, 1, 2, 0, 64>(p, nstep, s);      // wave 64x128
-    case 3: return launch_w8<128, 192, 2, 2, 2, 3, 0, 64>(p, nstep, s);      // wave 64x96, K groups, 3 stages
-    case 4: return launch_w8<128, 256, 2, 2, 2, 3, 0, 64>(p, nstep, s);      // wave 64x128, K groups, 3 stages
+    case 0: return launch_w8<128, 384, 2, 2, 2, 2, 0, 64>(p, nstep, splits, s);      // wave 64x192, K groups, classic ring
+    case 1: return launch_w8<128, 384, 4, 2, 1, 2, 0, 64>(p, nstep, splits, s);      // wave 32x192
+    case 2: return launch_w8<256, 256, 4, 2, 1, 2, 0, 64>(p, nstep, splits, s);      // wave 64x128
+    case 3: return launch_w8<128, 192, 2, 2, 2, 3, 0, 64>(p, nstep, splits, s);      // wave 64x96, K groups, 3 stages
+    case 4: return launch_w8<128, 256, 2, 2, 2, 3, 0, 64>(p, nstep, splits, s);      // wave 64x128, K groups, 3 stages
     // ping-pong, fragments read in the M phase
-    case 5: return launch_w8<256, 256, 4, 2, 1, 2, 2, 64>(p, nstep, s);
-    case 6: return launch_w8<128, 384, 2, 2, 2, 2, 2, 64>(p, nstep, s);
+    case 5: return launch_w8<256, 256, 4, 2, 1, 2, 2, 64>(p, nstep, splits, s);
+    case 6: return launch_w8<128, 384, 2, 2, 2, 2, 2, 64>(p, nstep, splits, s);
     // ping-pong with prefetched fragments, 32-deep stages
-    case 7: return launch_w8<256, 256, 4, 2, 1, 4, 3, 32>(p, nstep, s);      // wave 64x128, 4 x 32 KB
-    case 8: return launch_w8<256, 384, 4, 2, 1, 4, 3, 32>(p, nstep, s);      // wave 64x192, 4 x 40 KB
-    case 9: return launch_w8<128, 384, 4, 2, 1, 4, 3, 32>(p, nstep, s);      // wave 32x192, 4 x 32 KB
-    case 10: return launch_w8<256, 128, 4, 2, 1, 4, 3, 32>(p, nstep, s);     // wave 64x64, 4 x 24 KB
-    case 11: return launch_w8<128, 256, 2, 4, 1, 4, 3, 32>(p, nstep, s);     // wave 64x64, 4 x 24 KB
+    case 7: return launch_w8<256, 256, 4, 2, 1, 4, 3, 32>(p, nstep, splits, s);      // wave 64x128, 4 x 32 KB
+    case 8: return launch_w8<256, 384, 4, 2, 1, 3, 3, 32>(p, nstep, splits, s);      // wave 64x192, 3 x 40 KB (register-bound: spills)
+    case 9: return launch_w8<128, 384, 4, 2, 1, 4, 3, 32>(p, nstep, splits, s);      // wave 32x192, 4 x 32 KB
+    case 10: return launch_w8<256, 128, 4, 2, 1, 4, 3, 32>(p, nstep, splits, s);     // wave 64x64, 4 x 24 KB
+    case 11: return launch_w8<128, 256, 2, 4, 1, 4, 3, 32>(p, nstep, splits, s);     // wave 64x64, 4 x 24 KB
     // classic ring with the refill pieces spread over the k16 steps
-    case 12: return launch_w8<128, 384, 4, 2, 1, 2, 4, 64>(p, nstep, s);
-    case 13: return launch_w8<256, 256, 4, 2, 1, 2, 4, 64>(p, nstep, s);
-    case 14: return launch_w8<128, 192, 2, 2, 2, 3, 4, 64>(p, nstep, s);
-    case 15: return launch_w8<128, 384, 2, 2, 2, 2, 4, 64>(p, nstep, s);
-    case 16: return launch_w8<128, 256, 2, 2, 2, 3, 4, 64>(p, nstep, s);
+    case 12: return launch_w8<128, 384, 4, 2, 1, 2, 4, 64>(p, nstep, splits, s);
+    case 13: return launch_w8<256, 256, 4, 2, 1, 2, 4, 64>(p, nstep, splits, s);
+    case 14: return launch_w8<128, 192, 2, 2, 2, 3, 4, 64>(p, nstep, splits, s);
+    case 15: return launch_w8<128, 384, 2, 2, 2, 2, 4, 64>(p, nstep, splits, s);
+    case 16: return launch_w8<128, 256, 2, 2, 2, 3, 4, 64>(p, nstep, splits, s);
+    // software-pipelined classic ring (fragments one k16 step ahead, barrier before the last step, refill in portions)
+    case 17: return launch_w8<128, 384, 4, 2, 1, 2, 5, 64>(p, nstep, splits, s);
+    case 18: return launch_w8<256, 256, 4, 2, 1, 2, 5, 64>(p, nstep, splits, s);
+    case 19: return launch_w8<128, 192, 2, 2, 2, 3, 5, 64>(p, nstep, splits, s);
+    case 20: return launch_w8<128, 256, 2, 2, 2, 3, 5, 64>(p, nstep, splits, s);
     default: t2v_set_error("t2v_gemm_w8: unknown configuration %d", cfg); return T2V_EINVAL;
   }
 }

@@ -190,7 +190,9 @@ def _gemm_workspace():
     dev = torch.cuda.current_device()
     buf = _gemm_ws.get(dev)
     if buf is None:
-        buf = _gemm_ws[dev] = torch.empty(16 << 20, dtype=torch.float32, device=f"cuda:{dev}")   # 64 MB
+        # 64 MB; zero-filled: its first 64 KB hold the arrival counters of the in-launch split-K reduction (t2v_abi.h), which
+        # every launch leaves zero
+        buf = _gemm_ws[dev] = torch.zeros(16 << 20, dtype=torch.float32, device=f"cuda:{dev}")
     return buf
 
 

@@ -85,6 +85,7 @@ class Attn(C.Structure):
     ]
 
 
+ABI_VERSION = 2          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
@@ -94,6 +95,8 @@ SYMBOLS = {
     "t2v_abi_version": ([], c_int),
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_gemm_w8": ([C.POINTER(Gemm), c_int, c_int, c_int, c_void_p], c_int),
+    "t2v_gemm_w8_configs": ([], c_int),
     "t2v_set_dropout_epoch": ([c_void_p], c_int),
     "t2v_gemm_tune_export": ([C.c_char_p, c_ll], c_ll),
     "t2v_gemm_tune_import": ([C.c_char_p], c_int),
@@ -160,8 +163,9 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        if l.t2v_abi_version() != 1:
-            raise RuntimeError("t2v_amd: ABI version mismatch")
+        if l.t2v_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"t2v_amd: ABI version mismatch (library {l.t2v_abi_version()}, binding {ABI_VERSION}): rebuild "
+                               f"with `python __graft_entry__.py`")
         _lib = l
         if os.path.exists(TUNE_TABLE) and os.environ.get("T2V_GEMM_TABLE", "1") != "0":
             with open(TUNE_TABLE, "rb") as f:       # shipped tile table: t2v_gemm never times candidates at run time
