@@ -189,8 +189,8 @@ def gemm_roofline(trainer, batch):
         v = kev.ms(inner) if (kev is not None and inner is not None) else None
         return v if v is not None and v > 0 else s.elapsed_time(e)
 
-    def timed(**kw):
-        _, s, e, inner = run_timed(lambda: orig(**kw))
+    def timed(cs=None, **kw):
+        ret, s, e, inner = run_timed(lambda: orig(cs=cs, **kw))
         z = max(1, kw.get("batch", 1))
         flops = 2.0 * kw["M"] * kw["N"] * kw["K"] * z
         geom = kw.get("geom")
@@ -209,6 +209,7 @@ def gemm_roofline(trainer, batch):
             # the (3,1,1) Conv3d launches (forward + backward-data): SURVEY 8(d) bytes = x once + y once + weights once
             taps = 3
             conv3d.append((flops, (kw["M"] * (kw["K"] // taps) + kw["M"] * kw["N"] + kw["N"] * kw["K"]) * 2.0, s, e, inner))
+        return ret
 
     orig_pair = F.launch_gemm_pair
 
@@ -224,7 +225,7 @@ def gemm_roofline(trainer, batch):
     nv = F.nv
     orig_call = nv.call
 
-    NORM = {"t2v_gn_stats": (2, "gn_fwd"), "t2v_gn_apply": (4, "gn_fwd"), "t2v_gn_bwd_stats": (4, "gn_bwd"),
+    NORM = {"t2v_gn_stats": (2, "gn_fwd"), "t2v_gn_apply": (4, "gn_fwd"), "t2v_gn_finish": (None, "gn_finish"), "t2v_gn_bwd_stats": (4, "gn_bwd"),
             "t2v_gn_bwd_apply": (6, "gn_bwd"), "t2v_layernorm_fwd": (None, "ln_fwd"), "t2v_layernorm_bwd": (None, "ln_bwd")}
 
     def timed_call(name, *a):
@@ -233,6 +234,9 @@ def gemm_roofline(trainer, batch):
         r, s, e, inner = run_timed(lambda: orig_call(name, *a))
         if name in NORM:
             pos, kind = NORM[name]
+            if name == "t2v_gn_finish":          # statistics from the GEMM epilogues' column sums: no pass over the activations
+                norms.append((kind, 0.0, 0.0, s, e, inner))
+                return r
             if pos is None:                      # layernorm_fwd(x,ldx,y,ldy,rows,C,..) / bwd(x,ldx,dy,lddy,dx,lddx,rows,C,..)
                 E = float(a[4] * a[5]) if name.endswith("fwd") else float(a[6] * a[7])
                 moved = 2 * E * 2 if name.endswith("fwd") else (3 + (1 if a[-3] else 0)) * E * 2
@@ -313,11 +317,14 @@ def gemm_roofline(trainer, batch):
         if rs:
             ns[f"{kind}_attention_core"] = both_roofs(sum(r[1] for r in rs), sum(r[2] for r in rs),
                                                       sum(dur(r[3], r[4], r[5]) for r in rs), len(rs))
-    for kind in ("gn_fwd", "gn_bwd", "ln_fwd", "ln_bwd"):
+    for kind in ("gn_fwd", "gn_bwd", "gn_finish", "ln_fwd", "ln_bwd"):
         rs = [r for r in norms if r[0] == kind]
         if rs:
             ms = sum(dur(r[3], r[4], r[5]) for r in rs)
             alg, moved = sum(r[1] for r in rs), sum(r[2] for r in rs)
+            if kind == "gn_finish":
+                ns["groupnorm_finish(statistics from GEMM-epilogue column sums, fwd+bwd)"] = {"launches": len(rs), "ms_per_step": round(ms, 3)}
+                continue
             ns[{"gn_fwd": "groupnorm_fwd(stats+apply)", "gn_bwd": "groupnorm_bwd(stats+apply)", "ln_fwd": "layernorm_fwd",
                 "ln_bwd": "layernorm_bwd"}[kind]] = {
                 "launches": len(rs), "ms_per_step": round(ms, 3), "algorithmic_GB_per_step": round(alg / 1e9, 3),

@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 2   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
+#define T2V_ABI_VERSION 3   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -107,8 +107,25 @@ typedef struct {
   int raster_n;
   /* dropout epoch: device counter folded into drop_seed (see t2v_set_dropout_epoch); NULL = the process-wide one (or none) */
   const unsigned long long* drop_epoch;
+  /* optional column statistics of the stored output (GroupNorm fusion: the statistics pass of the F.group_norm that consumes
+   * this layer's output — or, in backward, of the GroupNorm whose output this layer consumed — rides in the epilogue, see
+   * t2v_gn_finish).  colsum: fp32 [4 + ceil(M / BMt) * Nb * 2], Nb = n_split > 0 ? n_split : N; word 0 = BMt (int: the tile
+   * rows of the kernel that ran), word 1 = Nb, then per (tile row, column) two fixed-order sums over the tile's rows of the
+   * bf16-ROUNDED stored values y:
+   *   cs_mode 1: (sum y, sum y^2)
+   *   cs_mode 2: y = dL/d(GroupNorm output); with xh = (cs_x - mean) * rstd of the forward statistics cs_sums [ndomains, G, 2]
+   *              (a domain = cs_domain_rows consecutive rows), z = xh * gamma + beta, dz = y * silu'(z) if cs_silu else y:
+   *              (sum dz * gamma, sum dz * gamma * xh) — the two sums of t2v_gn_bwd_stats.
+   * Honoured only by the kernels t2v_gemm_colsum_rows() reports (ask first; 0 = not available for this descriptor, leave
+   * colsum NULL); tiles never straddle a domain when BMt divides cs_domain_rows. */
+  float* colsum; int cs_mode; int cs_domain_rows;
+  const void* cs_x; long long cs_ldx; const float* cs_sums; const float* cs_gamma; const float* cs_beta; float cs_eps;
+  int cs_G; int cs_silu;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
+/* Tile rows BMt of the kernel t2v_gemm will run for this descriptor if that kernel can emit `colsum`, else 0 (deterministic:
+ * shipped tile table / heuristic; 0 during live tuning runs). */
+int t2v_gemm_colsum_rows(const T2VGemm* p);
 /* Pinned launch on one of the 8-wave, one-workgroup-per-CU configurations of csrc/gemm_w8.hip (what t2v_gemm selects through
  * the tile table for lean descriptors: K%64==0, window C%64==0, bf16 output, no dropout / batch); for tuning runs, the
  * configuration probes (scripts/w8_probe.py) and the kernel tests.  cfg: configuration index (t2v_gemm_w8_configs() of them);
@@ -160,6 +177,10 @@ int t2v_smallconv(const T2VSmallConv* p, t2v_stream_t stream);
 long long t2v_gn_workspace_floats(int ndomains, int G);
 int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows_per_domain, int C, int G,
                  float* sums, float* workspace, t2v_stream_t stream);
+/* statistics from the per-tile column sums a GEMM epilogue left in `colsum` (T2VGemm.colsum, either mode): sums[d, g, :] =
+ * fixed-order sum over the tiles of domain d and the columns of group g.  Needs rows_per_domain % BMt == 0 (checked by the
+ * caller against t2v_gemm_colsum_rows; the kernel writes NaN otherwise). */
+int t2v_gn_finish(const float* colsum, int ndomains, int rows_per_domain, int C, int G, float* sums, t2v_stream_t stream);
 int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy, int ndomains, int rows_per_domain, int C, int G,
                  const float* sums, const float* gamma, const float* beta, float eps, int silu,
                  float drop_p, unsigned long long drop_seed, t2v_stream_t stream);

@@ -841,3 +841,160 @@ def test_attention_deferred_rescale_branch():
                     F.SeqLayout(nb, S, S, 0, 1))
     assert relerr(o, ref.view(-1, C)) < TOL
     assert float((o.float().cpu() - ref.view(-1, C)).abs().max()) < 0.06
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 8-wave GEMM configurations (csrc/gemm_w8.hip) through the C ABI: every configuration, column steps, in-launch split-K
+def _w8_problem(M, N, rc, K, taps, res, seed=0):
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    g = torch.Generator().manual_seed(seed)
+    cin = K // taps
+    geom, x4 = None, None
+    if taps == 9:
+        nimg, side = 2, int((M // 2) ** 0.5)
+        assert nimg * side * side == M
+        geom = F.ConvCfg.conv2d(nimg, side, side, 3, 1, 1).fwd_geom(cin)
+    elif taps == 3:
+        geom = F.ConvCfg.conv3d_t(1, 4, M // 4).fwd_geom(cin)
+    a = _bf(torch.randn(M, cin, generator=g)).cuda()
+    w = _bf(torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = _bf(torch.randn(M, N, generator=g)).cuda() if res else None
+    d = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    kw = dict(M=M, N=N + rc, K=K, A=a.data_ptr(), lda=cin, B=w.data_ptr(), ldb=K, D=d.data_ptr(), ldd=N, bias=b.data_ptr(),
+              a_mode=1 if geom is not None else 0, geom=geom, R=nv.ptr(r), ldr=N if res else 0)
+    keep = [a, w, b, r, d]
+    t = None
+    if rc:
+        w2 = _bf(torch.randn(rc, K, generator=g) * K ** -0.5).cuda()
+        t = torch.empty(M, rc, dtype=torch.bfloat16, device="cuda")
+        kw.update(B2=w2.data_ptr(), ldb2=K, n_split=N, D2=t.data_ptr(), ldd2=rc)
+        keep += [w2, t]
+    return kw, d, t, keep
+
+
+@pytest.mark.parametrize("M,N,rc,K,taps,res", [(512, 320, 16, 320, 1, 1), (1152, 640, 16, 1920, 3, 0), (1152, 320, 16, 2880, 9, 1),
+                                                (300, 1280, 48, 1280, 1, 0), (2048, 128, 0, 1152, 9, 0)])
+def test_w8_configurations_match_the_table_kernels(M, N, rc, K, taps, res):
+    """Every 8-wave configuration x (whole-BN / partial column step) x (no split, 2, 3 K splits) against the 4-wave kernel the
+    heuristic picks for the same descriptor (itself checked against torch above).  K groups and splits change the summation
+    order: tolerance 1e-2 of the output scale; configurations without either must be bit-identical."""
+    import ctypes as C
+    import os
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    kw, d, t, keep = _w8_problem(M, N, rc, K, taps, res, seed=M + K)
+    desc = F.make_gemm(**kw)
+    os.environ["T2V_GEMM_FORCE_CFG"] = "0,2,1"            # 128x128 4-wave tile: the reference for this test
+    try:
+        nv.call("t2v_gemm", C.byref(desc), nv.stream())
+    finally:
+        del os.environ["T2V_GEMM_FORCE_CFG"]
+    torch.cuda.synchronize()
+    ref, reft = d.float().clone(), (t.float().clone() if rc else None)
+    scale = float(ref.abs().max())
+    lib = nv.lib()
+    ncfg = lib.t2v_gemm_w8_configs()
+    assert ncfg >= 17
+    for cfg in range(ncfg):
+        if cfg == 8:
+            continue                                      # (register-bound experiment, not in the production set)
+        for nstep, splits in ((0, 1), (160, 1), (0, 2), (96, 3)):
+            d.zero_()
+            if rc:
+                t.zero_()
+            nv.call("t2v_gemm_w8", C.byref(desc), cfg, nstep, splits, nv.stream())
+            torch.cuda.synchronize()
+            err = float((d.float() - ref).abs().max()) / scale
+            if rc:
+                err = max(err, float((t.float() - reft).abs().max()) / float(reft.abs().max()))
+            assert err < 1e-2, (cfg, nstep, splits, err)
+    ws = F._gemm_workspace()
+    assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "split-K counters must be left zero"
+
+
+@pytest.mark.parametrize("M,C_,K,taps,rpd,res", [(1024, 320, 960, 3, 256, 1), (2048, 640, 640, 1, 1024, 0), (512, 320, 2880, 9, 256, 1)])
+def test_gemm_epilogue_groupnorm_statistics(M, C_, K, taps, rpd, res):
+    """T2VGemm.colsum: the GroupNorm sums a GEMM epilogue leaves behind + t2v_gn_finish against the standalone statistics
+    kernels on the stored output — forward (sum y, sum y^2) and backward (sum dz*gamma, sum dz*gamma*xh, SiLU on and off)."""
+    import ctypes as C
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    G = 32
+    nd = M // rpd
+    lib = nv.lib()
+    # a w8 configuration must be the table's / heuristic's choice for colsum to be available: pin one for the test
+    import os
+    os.environ["T2V_GEMM_FORCE_CFG"] = "114,0,1"
+    try:
+        kw, d, t, keep = _w8_problem(M, C_, 16, K, taps, res, seed=7 + M)
+        # ---- mode 1
+        info = F.launch_gemm(cs={"mode": 1}, **kw)
+        assert info is not None, "the pinned 8-wave configuration must report column statistics"
+        buf, bm, mm, nb = info
+        assert mm == M and nb == C_ and rpd % bm == 0
+        sums = torch.empty(nd * G * 2, device="cuda")
+        nv.call("t2v_gn_finish", buf.data_ptr(), nd, rpd, C_, G, sums.data_ptr(), nv.stream())
+        ref = torch.empty_like(sums)
+        ws = F._gn_workspace(nd, G, d.device)
+        nv.call("t2v_gn_stats", d.data_ptr(), C_, nd, rpd, C_, G, ref.data_ptr(), ws.data_ptr(), nv.stream())
+        torch.cuda.synchronize()
+        assert relerr(sums, ref) < 1e-5
+        # ---- mode 2: the GEMM output plays dL/d(norm output); x, gamma, beta of the norm are independent tensors
+        g = torch.Generator().manual_seed(11)
+        x = _bf(torch.randn(M, C_, generator=g) * 2 + 0.5).cuda()
+        gamma = (torch.randn(C_, generator=g) * 0.5 + 1).cuda()
+        beta = (torch.randn(C_, generator=g) * 0.3).cuda()
+        fs = torch.empty(nd * G * 2, device="cuda")
+        nv.call("t2v_gn_stats", x.data_ptr(), C_, nd, rpd, C_, G, fs.data_ptr(), ws.data_ptr(), nv.stream())
+        kw2 = dict(kw)
+        kw2["R"], kw2["ldr"] = None, 0
+        for silu in (1, 0):
+            info = F.launch_gemm(cs={"mode": 2, "x": x.data_ptr(), "ldx": C_, "sums": fs.data_ptr(), "gamma": gamma.data_ptr(),
+                                     "beta": beta.data_ptr(), "eps": 1e-5, "G": G, "silu": silu, "domain_rows": rpd}, **kw2)
+            assert info is not None
+            bs = torch.empty(nd * G * 2, device="cuda")
+            nv.call("t2v_gn_finish", info[0].data_ptr(), nd, rpd, C_, G, bs.data_ptr(), nv.stream())
+            bref = torch.empty_like(bs)
+            nv.call("t2v_gn_bwd_stats", x.data_ptr(), C_, d.data_ptr(), C_, nd, rpd, C_, G, fs.data_ptr(), gamma.data_ptr(),
+                    beta.data_ptr(), 1e-5, silu, 0.0, 0, bref.data_ptr(), ws.data_ptr(), None, None, nv.stream())
+            torch.cuda.synchronize()
+            assert relerr(bs, bref) < 1e-4, silu
+    finally:
+        del os.environ["T2V_GEMM_FORCE_CFG"]
+
+
+def test_groupnorm_fusion_end_to_end_matches_the_unfused_ops():
+    """resnet-like chain conv -> GroupNorm(SiLU) -> conv with the statistics riding in the GEMM epilogues (forward and
+    backward) against the same chain with T2V_GN_FUSE off: same outputs and input gradients to bf16 rounding."""
+    import os
+    import t2v_amd.functional as F
+    g = torch.Generator().manual_seed(3)
+    nimg, H, W, Cc = 4, 16, 16, 320
+    x0 = _bf(torch.randn(nimg * H * W, Cc, generator=g))
+    w1 = torch.randn(Cc, Cc, 3, 3, generator=g) * (9 * Cc) ** -0.5
+    w2 = torch.randn(Cc, Cc, 3, 3, generator=g) * (9 * Cc) ** -0.5
+    gam, bet = torch.randn(Cc, generator=g) * 0.3 + 1, torch.randn(Cc, generator=g) * 0.2
+    dy = _bf(torch.randn(nimg * H * W, Cc, generator=g))
+    cfg = F.ConvCfg.conv2d(nimg, H, W, 3, 1, 1)
+    os.environ["T2V_GEMM_FORCE_CFG"] = "114,0,1"
+    outs = []
+    try:
+        for fuse in (True, False):
+            F._cs_enabled = fuse
+            xd = _dev(x0)
+            ws = [_dev(w1, False), _dev(w2, False)]
+            gd, bd = _dev(gam, False), _dev(bet, False)
+            h = F.conv_linear(xd, ws[0], None, cfg, colsum=True)
+            assert hasattr(h, "_t2v_cs") == fuse
+            a = F.group_norm(h, gd, bd, 32, 1e-5, True, nimg)
+            y = F.conv_linear(a, ws[1], None, cfg)
+            y.backward(dy.cuda())
+            torch.cuda.synchronize()
+            outs.append((y.detach().float().cpu(), xd.grad.float().cpu()))
+    finally:
+        F._cs_enabled = os.environ.get("T2V_GN_FUSE", "1") != "0"
+        del os.environ["T2V_GEMM_FORCE_CFG"]
+    assert relerr(outs[0][0], outs[1][0]) < 5e-3
+    assert relerr(outs[0][1], outs[1][1]) < 5e-3

@@ -89,6 +89,7 @@ void t2v_set_error(const char* fmt, ...);
 // gemm_w8.hip: 8-wave one-workgroup-per-CU GEMM configurations (descriptor already validated by gemm.hip)
 int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStream_t s);
 extern "C" int t2v_gemm_w8_configs(void);
+int t2v_gemm_w8_bm(int cfg);
 #define T2V_CHECK_ARG(cond, ...)          \
   do {                                    \
     if (!(cond)) {                        \

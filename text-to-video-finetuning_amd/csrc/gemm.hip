@@ -980,6 +980,8 @@ struct DmaCfg {
 DmaCfg heuristic_cfg(const T2VGemm& p);
 
 int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
+  T2V_CHECK_ARG(!(p.colsum && p.cs_mode != 0) || (c.tile >= W8_BASE && w8_ok(p)),
+                "t2v_gemm: colsum requested but the kernel selected for this descriptor cannot emit it (ask t2v_gemm_colsum_rows first)");
   if (c.tile >= W8_BASE) {
     if (w8_ok(p)) return t2v_gemm_w8_launch(p, c.tile - W8_BASE, c.stages * 32, c.split, s);
     return launch_dma_cfg(p, heuristic_cfg(p), s);     // (a table entry met a descriptor outside the 8-wave domain)
@@ -1381,6 +1383,17 @@ extern "C" int t2v_gemm_w8(const T2VGemm* pp, int cfg, int nstep, int splits, t2
   if (int e = check_gemm(*pp)) return e;
   T2V_CHECK_ARG(w8_ok(*pp), "t2v_gemm_w8: descriptor outside the 8-wave kernels' domain (K%%64, C%%64, bf16 output, no dropout/batch)");
   return t2v_gemm_w8_launch(*pp, cfg, nstep, splits, (hipStream_t)stream);
+}
+
+extern "C" int t2v_gemm_colsum_rows(const T2VGemm* pp) {
+  if (!pp || !w8_ok(*pp) || check_gemm(*pp) != T2V_OK) return 0;
+  if (g_autotune < 0) {
+    const char* e = getenv("T2V_GEMM_AUTOTUNE");
+    g_autotune = !e ? 1 : (e[0] == '0' ? 0 : ((e[0] == 'l' || e[0] == '2') ? 2 : 1));
+  }
+  if (g_autotune == 2) return 0;                              // tuning run: the tile is not known before the launch
+  const DmaCfg c = pick_cfg(*pp, nullptr);
+  return c.tile >= W8_BASE ? t2v_gemm_w8_bm(c.tile - W8_BASE) : 0;
 }
 
 extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {

@@ -529,6 +529,30 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       }
     }
   }
+  // ---- column statistics of the stored tile (T2VGemm.colsum, GroupNorm fusion): every thread accumulates its 8 columns over
+  // the rows it writes; the RPI threads of a column chunk are combined in fixed order through LDS after the last pass
+  const int Nb = p.n_split > 0 ? p.n_split : N;
+  const int cs_mode = p.colsum ? p.cs_mode : 0;
+  float cs1[8], cs2[8], c_mu[8], c_rs[8], c_g[8], c_b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs1[e] = cs2[e] = c_mu[e] = c_rs[e] = c_g[e] = c_b[e] = 0.f;
+  const bf16_t* CX = nullptr;
+  if (cs_mode == 2 && cact && !rankcol) {
+    CX = (const bf16_t*)p.cs_x;
+    const int cpg = Nb / p.cs_G;
+    const int dom = (int)(m0 / p.cs_domain_rows);
+    const float icnt = 1.f / ((float)p.cs_domain_rows * (float)cpg);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col + e;
+      const float* sp = p.cs_sums + ((long long)dom * p.cs_G + c / cpg) * 2;
+      const float mu = sp[0] * icnt;
+      c_mu[e] = mu;
+      c_rs[e] = rsqrtf(fmaxf(sp[1] * icnt - mu * mu, 0.f) + p.cs_eps);
+      c_g[e] = p.cs_gamma[c];
+      c_b[e] = p.cs_beta[c];
+    }
+  }
   // ---- split-K hand-off (splits > 1).  The splits of a tile draw a ticket when their K loop is done; the LAST one keeps its
   // partial tile in LDS / registers and becomes the reducer, the others write theirs as fp32 rows to the caller's workspace
   // (slab [tile][z]) and then count themselves done.  The reducer waits for splits-1 done marks (those workgroups finished
@@ -570,8 +594,15 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   for (int ps = 0; ps < FM * WRP; ++ps) {
     const int i = ps / WRP, h = ps % WRP;
     // residual chunks of this pass: requested now, consumed after the staging barriers
-    bf16x8 rv[ITERS];
-    if (R) {
+    bf16x8 rv[ITERS];                                // (cs_mode 2 excludes a residual: the same registers hold the x rows)
+    if (CX && role != 1) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int rl = r0 + RPI * it;
+        const unsigned row = (unsigned)m0 + (h * WPP + (rl >> 5)) * TM + i * 32 + (rl & 31);
+        if (rl < PROWS && row < (unsigned)M) rv[it] = *(const bf16x8*)(CX + row * (unsigned)p.cs_ldx + col);
+      }
+    } else if (R) {
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const int rl = r0 + RPI * it;
@@ -663,12 +694,62 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
         }
-        if (R) {
+        if (R && !CX) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += beta * bf2f((unsigned short)rv[it][e]);
         }
-        *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = pack8bf(v);
+        const bf16x8 ov = pack8bf(v);
+        *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = ov;
+        if (cs_mode == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float q = bf2f((unsigned short)ov[e]);
+            cs1[e] += q;
+            cs2[e] += q * q;
+          }
+        } else if (cs_mode == 2) {                   // the two sums of gn_stats_kernel<true> (norm.hip), same arithmetic
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (bf2f((unsigned short)rv[it][e]) - c_mu[e]) * c_rs[e];
+            float dz = bf2f((unsigned short)ov[e]);
+            if (p.cs_silu) {
+              const float zz = xh * c_g[e] + c_b[e];
+              const float sg = sigmoid_f(zz);
+              dz *= sg * (1.f + zz * (1.f - sg));
+            }
+            cs1[e] += dz * c_g[e];
+            cs2[e] += dz * c_g[e] * xh;
+          }
+        }
       }
+    }
+  }
+  if (cs_mode != 0 && role != 1) {
+    __syncthreads();                                 // staging buffer free: [RPI][BN][2] partials of the column chunks
+    float* red = (float*)smem;
+    if (cact && !rankcol) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[((r0 * BN) + cc * 8 + e) * 2] = cs1[e];
+        red[((r0 * BN) + cc * 8 + e) * 2 + 1] = cs2[e];
+      }
+    }
+    __syncthreads();
+    for (int c2 = tid; c2 < BN; c2 += NT) {
+      const int gc = n0 + c2;
+      if (c2 >= ncols || gc >= Nb) continue;
+      float a0 = 0.f, a1 = 0.f;
+      for (int q = 0; q < RPI; ++q) {                // fixed order
+        a0 += red[((q * BN) + c2) * 2];
+        a1 += red[((q * BN) + c2) * 2 + 1];
+      }
+      float* o = p.colsum + 4 + ((long long)tm * Nb + gc) * 2;
+      o[0] = a0;
+      o[1] = a1;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      ((int*)p.colsum)[0] = BM;
+      ((int*)p.colsum)[1] = Nb;
     }
   }
   if (writer) {
@@ -694,6 +775,9 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   constexpr int EPI = (WM * 32 * BN * 4 > 128 * 1024 ? WM / 2 : WM) * 32 * BN * 4;
   constexpr int SMEM = (RING > EPI ? RING : EPI) + 16;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
+  T2V_CHECK_ARG(!(p.colsum && p.cs_mode == 2) || (!p.R && p.cs_x && p.cs_sums && p.cs_gamma && p.cs_beta && p.cs_G > 0 &&
+                                                   p.cs_domain_rows % BM == 0 && p.cs_ldx % 8 == 0),
+                "t2v_gemm_w8: colsum mode 2 needs x / sums / gamma / beta, no residual, and tiles inside a domain");
   T2V_CHECK_ARG(p.n_split <= 0 || p.n_split % (64 / (BKT / 8)) == 0,
                 "t2v_gemm_w8: n_split=%d must be a multiple of %d for this configuration", p.n_split, 64 / (BKT / 8));
   auto kern = gemm_w8_kernel<BM, BN, WM, WN, KG, NSTAGE, SCHED, BKT>;
@@ -733,6 +817,11 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
 // Number of W8 configurations and a pinned-configuration launch (tile table / tuning / diagnostics).  The caller (gemm.hip)
 // has already validated the descriptor and checked that the lean loader and the bf16 epilogue apply.
 extern "C" int t2v_gemm_w8_configs(void) { return 21; }
+// tile rows of a configuration (t2v_gemm_colsum_rows)
+int t2v_gemm_w8_bm(int cfg) {
+  static const int bm[] = {128, 128, 256, 128, 128, 256, 128, 256, 256, 128, 256, 128, 128, 256, 128, 128, 128, 128, 256, 128, 128};
+  return cfg >= 0 && cfg < (int)(sizeof(bm) / sizeof(bm[0])) ? bm[cfg] : 0;
+}
 int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStream_t s) {
   switch (cfg) {
     //                       BM   BN  WM WN KG NS SCHED BK

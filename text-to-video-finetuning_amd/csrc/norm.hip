@@ -415,6 +415,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ GroupNorm statistics from GEMM-epilogue column sums
+// grid (G, ndomains), 64 threads: thread i owns items i, i+64, .. of the (tile, column-of-group) list — a fixed assignment —
+// and the 64 partials are added in lane order: bit-reproducible.
+__global__ __launch_bounds__(64) void gn_finish_kernel(const float* __restrict__ colsum, int rows_per_domain, int C, int G,
+                                                        float* __restrict__ out) {
+  __shared__ float sred[64 * 2];
+  const int bmt = ((const int*)colsum)[0], nb = ((const int*)colsum)[1];
+  const int g = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G;
+  float a0 = 0.f, a1 = 0.f;
+  if (bmt > 0 && rows_per_domain % bmt == 0 && nb == C) {
+    const int tpd = rows_per_domain / bmt;
+    const float* base = colsum + 4 + ((long long)d * tpd * nb + g * cpg) * 2;
+    const int items = tpd * cpg;
+    for (int i = tid; i < items; i += 64) {
+      const int t = i / cpg, c = i - t * cpg;
+      const float* q = base + ((long long)t * nb + c) * 2;
+      a0 += q[0];
+      a1 += q[1];
+    }
+  } else {
+    a0 = a1 = __builtin_nanf("");                   // a caller bug must not pass silently
+  }
+  sred[tid * 2] = a0;
+  sred[tid * 2 + 1] = a1;
+  __syncthreads();
+  if (tid < 2) {
+    float tot = 0.f;
+    for (int q = 0; q < 64; ++q) tot += sred[q * 2 + tid];
+    out[((long long)d * G + g) * 2 + tid] = tot;
+  }
+}
+
 int gn_check(const char* fn, int C, int G, long long ldx) {
   if (C <= 0 || G <= 0 || C % G != 0 || C % 8 != 0 || ldx % 8 != 0) {
     t2v_set_error("%s: need C%%G==0, C%%8==0, ld%%8==0 (C=%d G=%d ld=%lld)", fn, C, G, ldx);
@@ -455,6 +488,15 @@ extern "C" int t2v_gn_stats(const void* x, long long ldx, int ndomains, int rows
   T2V_LAUNCH(gn_stats_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0,
                      rows_per_domain, C, G, nullptr, nullptr, nullptr, 0.f, 0, 0.f, 0ull, (const unsigned long long*)nullptr, workspace + GN_MAX_DOMAINS, nullptr,
                      nullptr, sums, counters);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_gn_finish(const float* colsum, int ndomains, int rows_per_domain, int C, int G, float* sums,
+                             t2v_stream_t stream) {
+  if (int e = gn_check("t2v_gn_finish", C, G, 8)) return e;
+  T2V_CHECK_ARG(colsum && sums && ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_finish: bad args");
+  T2V_LAUNCH(gn_finish_kernel, dim3(G, ndomains), dim3(64), 0, (hipStream_t)stream, colsum, rows_per_domain, C, G, sums);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

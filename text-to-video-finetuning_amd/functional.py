@@ -148,8 +148,34 @@ def _pad_vec(v, n):
 
 
 # --------------------------------------------------------------------------- raw launches
-def launch_gemm(**kw):
-    nv.call("t2v_gemm", C.byref(make_gemm(**kw)), nv.stream())
+def launch_gemm(cs=None, **kw):
+    """Launch one GEMM-family problem.  `cs` asks for the GroupNorm column statistics of the stored output to ride in the
+    epilogue (T2VGemm.colsum): {"mode": 1} or {"mode": 2, "x", "ldx", "sums", "gamma", "beta", "eps", "G", "silu",
+    "domain_rows"}.  Returns (buffer, tile_rows) when the kernel the library selects can emit them, else None (the caller then
+    runs the separate statistics kernel)."""
+    g = make_gemm(**kw)
+    out = None
+    if cs is not None and _cs_enabled:
+        bm = int(nv.lib().t2v_gemm_colsum_rows(C.byref(g)))
+        if bm > 0 and (cs["mode"] == 1 or cs["domain_rows"] % bm == 0):
+            nb = kw["n_split"] if kw.get("n_split", 0) > 0 else kw["N"]
+            dev = torch.device("cuda", torch.cuda.current_device())
+            buf = torch.empty(4 + (-(-kw["M"] // bm)) * nb * 2, dtype=torch.float32, device=dev)
+            g.colsum, g.cs_mode = buf.data_ptr(), cs["mode"]
+            if cs["mode"] == 2:
+                g.cs_domain_rows = cs["domain_rows"]
+                g.cs_x, g.cs_ldx = cs["x"], cs["ldx"]
+                g.cs_sums, g.cs_gamma, g.cs_beta = cs["sums"], cs["gamma"], cs["beta"]
+                g.cs_eps, g.cs_G, g.cs_silu = cs["eps"], cs["G"], cs["silu"]
+            out = (buf, bm, kw["M"], nb)
+    nv.call("t2v_gemm", C.byref(g), nv.stream())
+    return out
+
+
+_cs_enabled = os.environ.get("T2V_GN_FUSE", "1") != "0"     # A/B switch: GroupNorm statistics in the GEMM epilogues
+_cs_last = [None]        # column statistics of the producer launched last (picked up by the wrapper that called it)
+_gn_last = [None]        # forward record of the GroupNorm evaluated last (attached to its output by the wrapper)
+_bwd_cs = {}             # data_ptr of a backward-data result -> (buffer, tile rows, M, C): consumed by the GroupNorm backward
 
 
 def launch_gemm_pair(kw_a, kw_b):
@@ -205,8 +231,9 @@ class _ConvLinear(torch.autograd.Function):
     """y = act(alpha * drop(x (*) W^T) + bias + rowbias[img]) + residual      (x (*) W = linear or sliding window)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, rowbias, residual, cfg, alpha, drop_p, drop_seed):
+    def forward(ctx, x, weight, bias, rowbias, residual, cfg, alpha, drop_p, drop_seed, colsum=False, gn=None):
         x = _mat(x, "x")
+        ctx.gn = gn
         wq = prepared_weight(weight, "fwd")
         npad = wq.shape[0]
         cin_p = wq.shape[1] // cfg.taps()
@@ -226,12 +253,13 @@ class _ConvLinear(torch.autograd.Function):
             rpr = M // rowbias.shape[0]
         if residual is not None:
             residual = _mat(residual, "residual")
-        launch_gemm(M=M, N=npad, K=wq.shape[1], A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=wq.shape[1],
-                    D=y.data_ptr(), ldd=npad, a_mode=nv.A_DENSE if cfg.kind == "linear" else nv.A_CONV,
-                    geom=None if cfg.kind == "linear" else cfg.fwd_geom(cin_p), bias=nv.ptr(b32),
-                    rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
-                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0, alpha=alpha, beta=1.0,
-                    drop_p=drop_p, drop_seed=drop_seed)
+        _cs_last[0] = launch_gemm(cs={"mode": 1} if (colsum and drop_p == 0.0) else None,
+                                  M=M, N=npad, K=wq.shape[1], A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=wq.shape[1],
+                                  D=y.data_ptr(), ldd=npad, a_mode=nv.A_DENSE if cfg.kind == "linear" else nv.A_CONV,
+                                  geom=None if cfg.kind == "linear" else cfg.fwd_geom(cin_p), bias=nv.ptr(b32),
+                                  rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
+                                  R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0, alpha=alpha, beta=1.0,
+                                  drop_p=drop_p, drop_seed=drop_seed)
         ctx.cfg, ctx.alpha, ctx.drop = cfg, alpha, (drop_p, drop_seed)
         ctx.has = (bias is not None and bias.requires_grad, rowbias is not None, residual is not None)
         ctx.bias_n = bias.shape[0] if bias is not None else 0
@@ -265,14 +293,15 @@ class _ConvLinear(torch.autograd.Function):
             cin_p = wb.shape[0]
             if cfg.kind == "linear":
                 dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
-                launch_gemm(M=M, N=cin_p, K=npad, A=g.data_ptr(), lda=_ld(g), B=wb.data_ptr(), ldb=wb.shape[1],
-                            D=dx.data_ptr(), ldd=cin_p, alpha=alpha)
+                _note_bwd_cs(dx, launch_gemm(cs=_gn_bwd_request(ctx.gn, M, cin_p), M=M, N=cin_p, K=npad, A=g.data_ptr(), lda=_ld(g),
+                                             B=wb.data_ptr(), ldb=wb.shape[1], D=dx.data_ptr(), ldd=cin_p, alpha=alpha))
             else:
                 Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
                 Mi = cfg.nimg * Hv * Wv
                 dxv = torch.empty(Mi, cin_p, dtype=BF16, device=dy.device)
-                launch_gemm(M=Mi, N=cin_p, K=wb.shape[1], A=g.data_ptr(), lda=_ld(g), B=wb.data_ptr(), ldb=wb.shape[1],
-                            D=dxv.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(npad), alpha=alpha)
+                _note_bwd_cs(dxv, launch_gemm(cs=None if cfg.up else _gn_bwd_request(ctx.gn, Mi, cin_p), M=Mi, N=cin_p, K=wb.shape[1],
+                                              A=g.data_ptr(), lda=_ld(g), B=wb.data_ptr(), ldb=wb.shape[1], D=dxv.data_ptr(),
+                                              ldd=cin_p, a_mode=nv.A_CONV, geom=cfg.bwd_geom(npad), alpha=alpha))
                 if cfg.up:
                     dx = torch.empty(cfg.nimg * cfg.H * cfg.W, cin_p, dtype=BF16, device=dy.device)
                     nv.call("t2v_pool2x2_sum", dxv.data_ptr(), cin_p, dx.data_ptr(), cin_p, cfg.nimg, cfg.H, cfg.W, cin_p,
@@ -290,13 +319,27 @@ class _ConvLinear(torch.autograd.Function):
                         geom=None if cfg.kind == "linear" else cfg.fwd_geom(cin_p), D=dwp.data_ptr(), ldd=kw,
                         out_mode=nv.OUT_F32_ATOMIC, alpha=alpha, split_k=_split_k(tiles, M))
             dw = _unprep_weight_grad(dwp, weight, cfg)
-        return dx, dw, db, drb, dres, None, None, None, None
+        return dx, dw, db, drb, dres, None, None, None, None, None, None
 
 
 def launch_gemm_dropmask(dy, out, drop_p, drop_seed):
     """Re-apply the GEMM epilogue's dropout mask (index = row * N + col) to the incoming gradient."""
     nv.call("t2v_dropout_mask", dy.data_ptr(), _ld(dy), out.data_ptr(), _ld(out), dy.shape[0], dy.shape[1], drop_p,
             drop_seed, nv.stream())
+
+
+def _gn_bwd_request(gn, M, C_):
+    """Column-statistics request for a backward-data launch whose result is the gradient of a GroupNorm output `gn` recorded:
+    the two sums of t2v_gn_bwd_stats ride in the epilogue (mode 2).  None when the record does not fit this launch."""
+    if gn is None or gn["drop_p"] > 0.0 or gn["x"].shape != (M, C_) or gn["want_pg"]:
+        return None
+    return {"mode": 2, "x": gn["x"].data_ptr(), "ldx": _ld(gn["x"]), "sums": gn["sums"].data_ptr(), "gamma": gn["g32"].data_ptr(),
+            "beta": gn["b32"].data_ptr(), "eps": gn["eps"], "G": gn["G"], "silu": gn["silu"], "domain_rows": gn["rpd"]}
+
+
+def _note_bwd_cs(dx, info):
+    if info is not None:
+        _bwd_cs[dx.data_ptr()] = info
 
 
 class _Dropout(torch.autograd.Function):
@@ -415,6 +458,11 @@ def _wgrad_staging(nbytes, device):
     if slot[1].device != device:
         slot[1] = torch.empty(_WQ_BYTES, dtype=torch.uint8, device=device)
     return slot
+
+
+def clear_bwd_colsums():
+    """Forget backward column statistics nobody consumed (called between steps: their buffers must not outlive the pass)."""
+    _bwd_cs.clear()
 
 
 def drop_pending_wgrads():
@@ -656,8 +704,9 @@ class _LoraMerged(torch.autograd.Function):
     its autograd, with no rank columns in the tile grid and no rank-update passes."""
 
     @staticmethod
-    def forward(ctx, x, down_w, up_w, bias, rowbias, residual, cfg, e, scale):
+    def forward(ctx, x, down_w, up_w, bias, rowbias, residual, cfg, e, scale, colsum=False, gn=None):
         x = _mat(x, "x")
+        ctx.gn = gn
         wq = e.weff_fwd
         npad, K = e.npad, e.taps * e.cin_p
         if x.shape[1] != e.cin_p or cfg.taps() != e.taps:
@@ -675,11 +724,12 @@ class _LoraMerged(torch.autograd.Function):
             rpr = M // rowbias.shape[0]
         if residual is not None:
             residual = _mat(residual, "residual")
-        launch_gemm(M=M, N=npad + e.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(), ldd=npad,
-                    a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(e.cin_p) if conv else None, bias=nv.ptr(b32),
-                    rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
-                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
-                    B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
+        _cs_last[0] = launch_gemm(cs={"mode": 1} if colsum else None,
+                                  M=M, N=npad + e.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=_ld(wq), D=y.data_ptr(),
+                                  ldd=npad, a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(e.cin_p) if conv else None,
+                                  bias=nv.ptr(b32), rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0,
+                                  rows_per_rb=rpr, R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
+                                  B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
         ctx.cfg, ctx.e, ctx.scale = cfg, e, scale
         ctx.has = (rowbias is not None, residual is not None)
         ctx.save_for_backward(x, rowbias, t)
@@ -703,18 +753,18 @@ class _LoraMerged(torch.autograd.Function):
             if cfg.kind == "linear":                   # [dx | dt] = dy [W_eff | U]: dt rides as rank columns
                 dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
                 dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)
-                launch_gemm(M=M, N=cin_p + e.rp, K=npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=_ld(wb),
-                            D=dx.data_ptr(), ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p,
-                            D2=dt.data_ptr(), ldd2=e.rp)
+                _note_bwd_cs(dx, launch_gemm(cs=_gn_bwd_request(ctx.gn, M, cin_p), M=M, N=cin_p + e.rp, K=npad, A=dy.data_ptr(),
+                                             lda=_ld(dy), B=wb.data_ptr(), ldb=_ld(wb), D=dx.data_ptr(), ldd=cin_p,
+                                             B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp))
             elif e.rp <= 32 and _wgrad_window_ok(cfg.fwd_geom(cin_p), M) and cfg.taps() in (1, 3, 9):
                 # stride-1 same-size window: the rank columns' weights exist only at the tap that gathers the row itself
                 bg = cfg.bwd_geom(npad)
                 dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
                 dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)
-                launch_gemm(M=M, N=cin_p + e.rp, K=cfg.taps() * npad, A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(),
-                            ldb=_ld(wb), D=dx.data_ptr(), ldd=cin_p, a_mode=nv.A_CONV, geom=bg, B2=e.up_w16.data_ptr(),
-                            ldb2=_ld(e.up_w16), n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp,
-                            b2_k0=(bg.py * bg.KW + bg.px) * npad, b2_klen=npad)
+                _note_bwd_cs(dx, launch_gemm(cs=_gn_bwd_request(ctx.gn, M, cin_p), M=M, N=cin_p + e.rp, K=cfg.taps() * npad,
+                                             A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=_ld(wb), D=dx.data_ptr(), ldd=cin_p,
+                                             a_mode=nv.A_CONV, geom=bg, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p,
+                                             D2=dt.data_ptr(), ldd2=e.rp, b2_k0=(bg.py * bg.KW + bg.px) * npad, b2_klen=npad))
             else:
                 Hv, Wv = cfg.H << cfg.up, cfg.W << cfg.up
                 Mi = cfg.nimg * Hv * Wv
@@ -728,11 +778,13 @@ class _LoraMerged(torch.autograd.Function):
                 else:
                     dx = dxv
         _lora_side_grads(x, dy.data_ptr(), _ld(dy), [dy, x, t, dt], cfg, e, scale, M, npad, cin_p, t=t, dt=dt)
-        return dx, None, None, None, drb, dres, None, None, None
+        return dx, None, None, None, drb, dres, None, None, None, None, None
 
 
-def lora_merged(x, bias, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None):
-    return _LoraMerged.apply(x, down_w, up_w, bias, rowbias, residual, cfg, entry, float(scale))
+def lora_merged(x, bias, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None, colsum=False):
+    _cs_last[0] = None
+    return _attach_cs(_LoraMerged.apply(x, down_w, up_w, bias, rowbias, residual, cfg, entry, float(scale), bool(colsum),
+                                        getattr(x, "_t2v_gn", None)))
 
 
 class _LoraGroupMerged(torch.autograd.Function):
@@ -926,8 +978,18 @@ def lora_layer(x, w_base, b_base, down_w, up_w, cfg, entry, scale, rowbias=None,
                             int(drop_seed))
 
 
-def conv_linear(x, weight, bias=None, cfg=LINEAR, rowbias=None, residual=None, alpha=1.0, drop_p=0.0, drop_seed=0):
-    return _ConvLinear.apply(x, weight, bias, rowbias, residual, cfg, float(alpha), float(drop_p), int(drop_seed))
+def _attach_cs(y):
+    """Hand the column statistics of the launch that produced `y` to whoever normalises it next (group_norm reads the attribute)."""
+    info, _cs_last[0] = _cs_last[0], None
+    if info is not None:
+        y._t2v_cs = info
+    return y
+
+
+def conv_linear(x, weight, bias=None, cfg=LINEAR, rowbias=None, residual=None, alpha=1.0, drop_p=0.0, drop_seed=0, colsum=False):
+    _cs_last[0] = None
+    return _attach_cs(_ConvLinear.apply(x, weight, bias, rowbias, residual, cfg, float(alpha), float(drop_p), int(drop_seed),
+                                        bool(colsum), getattr(x, "_t2v_gn", None)))
 
 
 # --------------------------------------------------------------------------- GroupNorm (+SiLU, +dropout)
@@ -946,20 +1008,27 @@ def _gn_workspace(ndomains, G, device):
 
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, G, eps, silu, ndomains, drop_p, drop_seed, passthrough=False):
+    def forward(ctx, x, gamma, beta, G, eps, silu, ndomains, drop_p, drop_seed, passthrough=False, cs=None):
         x = _mat(x, "x")
         rows, Cc = x.shape
         rpd = rows // ndomains
         g32, b32 = _f32(gamma), _f32(beta)
         sums = torch.empty(ndomains * G * 2, dtype=torch.float32, device=x.device)
-        ws = _gn_workspace(ndomains, G, x.device)
         s = nv.stream()
-        nv.call("t2v_gn_stats", x.data_ptr(), _ld(x), ndomains, rpd, Cc, G, sums.data_ptr(), ws.data_ptr(), s)
+        if cs is not None and cs[2] == rows and cs[3] == Cc and rpd % cs[1] == 0 and _ld(x) == Cc:
+            # the producing GEMM left per-tile column sums of x: a small finishing launch instead of a pass over x
+            nv.call("t2v_gn_finish", cs[0].data_ptr(), ndomains, rpd, Cc, G, sums.data_ptr(), s)
+        else:
+            ws = _gn_workspace(ndomains, G, x.device)
+            nv.call("t2v_gn_stats", x.data_ptr(), _ld(x), ndomains, rpd, Cc, G, sums.data_ptr(), ws.data_ptr(), s)
         y = torch.empty(rows, Cc, dtype=BF16, device=x.device)
         nv.call("t2v_gn_apply", x.data_ptr(), _ld(x), y.data_ptr(), Cc, ndomains, rpd, Cc, G, sums.data_ptr(),
                 g32.data_ptr(), b32.data_ptr(), eps, int(silu), drop_p, drop_seed, s)
         ctx.args = (G, eps, int(silu), ndomains, rpd, drop_p, drop_seed)
         ctx.save_for_backward(x, gamma, beta, sums)
+        # forward record for the layer that consumes y: its backward-data launch can then carry this norm's backward sums
+        _gn_last[0] = dict(x=x, sums=sums, g32=g32, b32=b32, G=G, eps=eps, silu=int(silu), rpd=rpd, drop_p=drop_p,
+                           want_pg=bool(gamma.requires_grad or beta.requires_grad))
         if passthrough:          # second output: x itself, for the residual use — its gradient is summed inside bwd_apply
             return y, x.detach()
         return y
@@ -969,7 +1038,7 @@ class _GroupNorm(torch.autograd.Function):
         x, gamma, beta, sums = ctx.saved_tensors
         G, eps, silu, ndomains, rpd, drop_p, drop_seed = ctx.args
         if dy is None:
-            return (dres,) + (None,) * 9
+            return (dres,) + (None,) * 10
         dy = _mat(dy if dy.stride(1) == 1 else dy.contiguous(), "dy")
         if dres is not None:
             dres = _mat(dres if dres.stride(1) == 1 else dres.contiguous(), "dres")
@@ -980,26 +1049,41 @@ class _GroupNorm(torch.autograd.Function):
         dgm = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         dbt = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         bsums = torch.empty(ndomains * G * 2, dtype=torch.float32, device=x.device)
-        ws = _gn_workspace(ndomains, G, x.device)
-        nv.call("t2v_gn_bwd_stats", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ndomains, rpd, Cc, G, sums.data_ptr(),
-                g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, bsums.data_ptr(), ws.data_ptr(), nv.ptr(dgm),
-                nv.ptr(dbt), s)
+        cs = _bwd_cs.pop(dy.data_ptr(), None)
+        if (cs is not None and not want_pg and drop_p == 0.0 and cs[2] == rows and cs[3] == Cc and rpd % cs[1] == 0
+                and _ld(dy) == Cc):
+            nv.call("t2v_gn_finish", cs[0].data_ptr(), ndomains, rpd, Cc, G, bsums.data_ptr(), s)
+        else:
+            ws = _gn_workspace(ndomains, G, x.device)
+            nv.call("t2v_gn_bwd_stats", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ndomains, rpd, Cc, G, sums.data_ptr(),
+                    g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, bsums.data_ptr(), ws.data_ptr(), nv.ptr(dgm),
+                    nv.ptr(dbt), s)
         dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
         nv.call("t2v_gn_bwd_apply", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, ndomains, rpd, Cc, G,
                 sums.data_ptr(), bsums.data_ptr(), g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed,
                 nv.ptr(dres), _ld(dres) if dres is not None else 0, s)
         return (dx, dgm.to(gamma.dtype) if want_pg else None, dbt.to(beta.dtype) if want_pg else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
+
+
+def _attach_gn(y):
+    rec, _gn_last[0] = _gn_last[0], None
+    if rec is not None and _cs_enabled:
+        y._t2v_gn = rec
+    return y
 
 
 def group_norm(x, gamma, beta, G, eps, silu, ndomains, drop_p=0.0, drop_seed=0):
-    return _GroupNorm.apply(x, gamma, beta, G, float(eps), bool(silu), int(ndomains), float(drop_p), int(drop_seed))
+    return _attach_gn(_GroupNorm.apply(x, gamma, beta, G, float(eps), bool(silu), int(ndomains), float(drop_p), int(drop_seed),
+                                       False, getattr(x, "_t2v_cs", None)))
 
 
 def group_norm_res(x, gamma, beta, G, eps, silu, ndomains, drop_p=0.0, drop_seed=0):
     """(group_norm(x), x_res): use `x_res` wherever x itself is consumed again (the residual around the normalised branch);
     the two gradients are then summed inside the backward-apply kernel instead of by a separate add."""
-    return _GroupNorm.apply(x, gamma, beta, G, float(eps), bool(silu), int(ndomains), float(drop_p), int(drop_seed), True)
+    y, xr = _GroupNorm.apply(x, gamma, beta, G, float(eps), bool(silu), int(ndomains), float(drop_p), int(drop_seed), True,
+                             getattr(x, "_t2v_cs", None))
+    return _attach_gn(y), xr
 
 
 # --------------------------------------------------------------------------- LayerNorm

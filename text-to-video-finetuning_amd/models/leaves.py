@@ -70,10 +70,11 @@ def _drop_p(mod):
     return float(mod.p) if (isinstance(mod, nn.Dropout) and mod.training) else 0.0
 
 
-def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None):
-    """Evaluate a Linear/Conv leaf (or a LoRA wrapper swapped in for it) on a token matrix."""
+def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
+    """Evaluate a Linear/Conv leaf (or a LoRA wrapper swapped in for it) on a token matrix.  `colsum`: the output feeds a
+    GroupNorm — let the GEMM epilogue leave that norm's statistics behind (functional.launch_gemm)."""
     if isinstance(mod, (nn.Linear, nn.Conv2d, nn.Conv3d)) and not hasattr(mod, "lora_A"):
-        return F.conv_linear(x, mod.weight, mod.bias, cfg, rowbias, residual)
+        return F.conv_linear(x, mod.weight, mod.bias, cfg, rowbias, residual, colsum=colsum)
     base = getattr(mod, "linear", None)
     if base is None:
         base = getattr(mod, "conv", None)
@@ -86,7 +87,7 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None):
                 and torch.is_grad_enabled()):
             if p == 0.0 and getattr(entry, "merge_scale", None) == float(mod.scale):   # merged weight W + s U D is current
                 return F.lora_merged(x, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry, float(mod.scale),
-                                     rowbias, residual)
+                                     rowbias, residual, colsum=colsum)
             if p == 0.0 or entry.rp in (8, 16, 24, 32, 48, 64, 96):
                 # LoRA branch kept apart from the weight: active dropout (the reference's default train mode), or merge off
                 return F.lora_layer(x, base.weight, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry,
@@ -197,13 +198,13 @@ class ResnetBlock2D(nn.Module):
         rb = None
         if temb is not None and self.time_emb_proj is not None:
             rb = run_layer(self.time_emb_proj, temb.act)          # [B, Cout]; broadcast over the B's F*h*w rows
-        h = run_layer(self.conv1, a, cfg3, rowbias=rb)
+        h = run_layer(self.conv1, a, cfg3, rowbias=rb, colsum=True)
         a2 = F.group_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, x.n,
                           _drop_p(self.dropout), _next_seed() if _drop_p(self.dropout) > 0 else 0)
         sc = xr
         if self.conv_shortcut is not None:
             sc = run_layer(self.conv_shortcut, xr, ConvCfg.conv2d(x.n, x.h, x.w, 1, 1, 0))
-        out = run_layer(self.conv2, a2, cfg3, residual=sc)
+        out = run_layer(self.conv2, a2, cfg3, residual=sc, colsum=True)      # (feeds the next module's GroupNorm)
         return Tok(out, x.n, x.h, x.w)
 
 
@@ -236,7 +237,7 @@ class TemporalConvLayer(nn.Module):
                 a, xr = F.group_norm_res(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
             else:
                 a = F.group_norm(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
-            cur = run_layer(conv, a, cfg, residual=xr if i == 3 else None)
+            cur = run_layer(conv, a, cfg, residual=xr if i == 3 else None, colsum=True)
         return Tok(cur, x.n, x.h, x.w)
 
 
@@ -365,7 +366,7 @@ class Transformer2DModel(nn.Module):
         klay = SeqLayout(x.n, ctx.S, ctx.S, 0, 1, x.n // ctx.B)
         for blk in self.transformer_blocks:
             t = blk(t, qlay, ctx.m, klay)
-        out = run_layer(self.proj_out, t, residual=xr)
+        out = run_layer(self.proj_out, t, residual=xr, colsum=True)
         return _Out(sample=Tok(out, x.n, x.h, x.w))
 
 
@@ -392,7 +393,7 @@ class TransformerTemporalModel(nn.Module):
         qlay = SeqLayout(B * hw, num_frames, num_frames * hw, 1, hw, hw)
         for blk in self.transformer_blocks:
             t = blk(t, qlay)
-        out = run_layer(self.proj_out, t, residual=xr)
+        out = run_layer(self.proj_out, t, residual=xr, colsum=True)
         return _Out(sample=Tok(out, x.n, x.h, x.w))
 
 
@@ -408,7 +409,7 @@ class Downsample2D(nn.Module):
             cfg = ConvCfg("conv", x.n, x.h, x.w, 3, 3, 2, 0, 0, 0, x.h // 2, x.w // 2)
         else:
             cfg = ConvCfg.conv2d(x.n, x.h, x.w, 3, 2, self.padding)
-        return Tok(run_layer(self.conv, x.m, cfg), x.n, cfg.Ho, cfg.Wo)
+        return Tok(run_layer(self.conv, x.m, cfg, colsum=True), x.n, cfg.Ho, cfg.Wo)
 
 
 class Upsample2D(nn.Module):
@@ -420,4 +421,4 @@ class Upsample2D(nn.Module):
         if output_size is not None and tuple(output_size) != (2 * x.h, 2 * x.w):
             raise RuntimeError("t2v_amd: only the exact 2x nearest upsample is implemented natively")
         cfg = ConvCfg.conv2d(x.n, x.h, x.w, 3, 1, 1, up=1)
-        return Tok(run_layer(self.conv, x.m, cfg), x.n, 2 * x.h, 2 * x.w)
+        return Tok(run_layer(self.conv, x.m, cfg, colsum=True), x.n, 2 * x.h, 2 * x.w)

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2v_hip.so")
-TUNE_TABLE = os.path.join(_HERE, "gemm_tune_gfx950.txt")
+TUNE_TABLE = os.environ.get("T2V_GEMM_TABLE_FILE") or os.path.join(_HERE, "gemm_tune_gfx950.txt")   # (override: A/B runs)
 
 c_void_p, c_int, c_ll, c_float, c_ull = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
 
@@ -59,6 +59,9 @@ class Gemm(C.Structure):
         ("b_tapflip", c_int), ("b2_k0", c_int), ("b2_klen", c_int),
         ("workspace", c_void_p), ("workspace_bytes", C.c_size_t), ("ws_split", c_int), ("raster_n", c_int),
         ("drop_epoch", c_void_p),
+        ("colsum", c_void_p), ("cs_mode", c_int), ("cs_domain_rows", c_int),
+        ("cs_x", c_void_p), ("cs_ldx", c_ll), ("cs_sums", c_void_p), ("cs_gamma", c_void_p), ("cs_beta", c_void_p),
+        ("cs_eps", c_float), ("cs_G", c_int), ("cs_silu", c_int),
     ]
 
 
@@ -85,7 +88,7 @@ class Attn(C.Structure):
     ]
 
 
-ABI_VERSION = 2          # include/t2v_abi.h T2V_ABI_VERSION
+ABI_VERSION = 3          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
@@ -95,6 +98,8 @@ SYMBOLS = {
     "t2v_abi_version": ([], c_int),
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_gemm_colsum_rows": ([C.POINTER(Gemm)], c_int),
+    "t2v_gn_finish": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "t2v_gemm_w8": ([C.POINTER(Gemm), c_int, c_int, c_int, c_void_p], c_int),
     "t2v_gemm_w8_configs": ([], c_int),
     "t2v_set_dropout_epoch": ([c_void_p], c_int),

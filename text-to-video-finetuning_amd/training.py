@@ -124,8 +124,9 @@ class FlatAdamW:
             self.merge.run()
 
     def zero_grad(self, set_to_none=False):
-        from .functional import drop_pending_wgrads
+        from .functional import clear_bwd_colsums, drop_pending_wgrads
         drop_pending_wgrads()              # leftovers of a backward pass that died half-way must not run against freed operands
+        clear_bwd_colsums()
         self._ensure_homed()
         self.flat_g_full.zero_()
 
