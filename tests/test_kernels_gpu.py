@@ -914,8 +914,9 @@ def test_w8_configurations_match_the_table_kernels(M, N, rc, K, taps, res):
     assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "split-K counters must be left zero"
 
 
+@pytest.mark.parametrize("force", ["114,0,1", "113,0,1", "2,2,1", "0,0,1", "112,5,2"])
 @pytest.mark.parametrize("M,C_,K,taps,rpd,res", [(1024, 320, 960, 3, 256, 1), (2048, 640, 640, 1, 1024, 0), (512, 320, 2880, 9, 256, 1)])
-def test_gemm_epilogue_groupnorm_statistics(M, C_, K, taps, rpd, res):
+def test_gemm_epilogue_groupnorm_statistics(M, C_, K, taps, rpd, res, force):
     """T2VGemm.colsum: the GroupNorm sums a GEMM epilogue leaves behind + t2v_gn_finish against the standalone statistics
     kernels on the stored output — forward (sum y, sum y^2) and backward (sum dz*gamma, sum dz*gamma*xh, SiLU on and off)."""
     import ctypes as C
@@ -924,9 +925,9 @@ def test_gemm_epilogue_groupnorm_statistics(M, C_, K, taps, rpd, res):
     G = 32
     nd = M // rpd
     lib = nv.lib()
-    # a w8 configuration must be the table's / heuristic's choice for colsum to be available: pin one for the test
+    # pin the kernel: 8-wave configurations (incl. a column step + K split) and 4-wave tiles of gemm.hip
     import os
-    os.environ["T2V_GEMM_FORCE_CFG"] = "114,0,1"
+    os.environ["T2V_GEMM_FORCE_CFG"] = force
     try:
         kw, d, t, keep = _w8_problem(M, C_, 16, K, taps, res, seed=7 + M)
         # ---- mode 1

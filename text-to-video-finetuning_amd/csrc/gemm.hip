@@ -19,7 +19,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <vector>
-#include "common.h"
+#include "colsum.h"
 
 namespace {
 
@@ -230,7 +230,7 @@ __device__ __forceinline__ void epi_prefetch(const T2VGemm& p, EpiPre<BM, BN, WM
 
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void epilogue_lean(const T2VGemm& p, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)],
-                                              unsigned char* smem, long long m0, int n0, const EpiPre<BM, BN, WM, WN>& pre) {
+                                              unsigned char* smem, long long m0, int n0, const EpiPre<BM, BN, WM, WN>& pre, int tm) {
   using E = EpiPre<BM, BN, WM, WN>;
   constexpr int NT = E::NT, FM = E::FM, FN = BN / (WN * 32), CPR = E::CPR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -239,6 +239,14 @@ __device__ __forceinline__ void epilogue_lean(const T2VGemm& p, f32x16 (&acc)[BM
   const float* bias = (const float*)p.bias;
   const bf16_t* rowbias = (const bf16_t*)p.rowbias;
   const bf16_t* R = (const bf16_t*)p.R;
+  // GroupNorm statistics of the stored tile (colsum.h): a thread keeps its column chunk over the passes when CPR divides NT
+  constexpr bool CS_OK = NT % CPR == 0;
+  const int cs_mode = (CS_OK && p.colsum) ? p.cs_mode : 0;
+  const int Nb = p.n_split > 0 ? p.n_split : p.N;
+  const int ccf = tid % CPR, rgf = tid / CPR, colf = n0 + ccf * 8;
+  const bool cs_act = cs_mode != 0 && colf < Nb;
+  CsState cst;
+  if (cs_mode != 0) cs_init(cst, p, cs_mode, cs_act, m0, colf, Nb);
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     if (i > 0) __syncthreads();
@@ -293,8 +301,18 @@ __device__ __forceinline__ void epilogue_lean(const T2VGemm& p, f32x16 (&acc)[BM
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += p.beta * bf2f((unsigned short)t[e]);
       }
-      *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = pack8bf(v);
+      const bf16x8 ov = pack8bf(v);
+      *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = ov;
+      if (cs_mode != 0) {
+        bf16x8 xrow = ov;
+        if (cs_mode == 2) xrow = *(const bf16x8*)((const bf16_t*)p.cs_x + row * (unsigned)p.cs_ldx + col);
+        cs_add(cst, cs_mode, ov, xrow, p.cs_silu);
+      }
     }
+  }
+  if (cs_mode != 0) {
+    __syncthreads();
+    cs_flush(cst, p, sC, cs_act, rgf, NT / CPR, ccf, BN, tid, NT, n0, min(BN, p.N - n0), Nb, tm, BM);
   }
 }
 
@@ -599,7 +617,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
   __syncthreads();                                               // ring is idle: reuse it for the epilogue staging
   if constexpr (LEAN) {
     if (epi_fast) {
-      epilogue_lean<BM, BN, WM, WN>(p, acc, smem, m0, n0, pre);
+      epilogue_lean<BM, BN, WM, WN>(p, acc, smem, m0, n0, pre, tm);
       return;
     }
   }
@@ -979,8 +997,22 @@ struct DmaCfg {
 
 DmaCfg heuristic_cfg(const T2VGemm& p);
 
+// tile rows of configuration `c` if its epilogue can emit T2VGemm.colsum for descriptor p, else 0
+int colsum_bm(const T2VGemm& p, const DmaCfg& c) {
+  if (!w8_ok(p)) return 0;
+  if (c.tile >= W8_BASE) return t2v_gemm_w8_bm(c.tile - W8_BASE);
+  static const int no_epi = [] { const char* e = getenv("T2V_GEMM_EPI"); return e && e[0] == '0'; }();
+  if (no_epi || c.split > 1) return 0;
+  switch (c.tile) {                       // the lean epilogue keeps a thread on one column chunk when BN/8 divides the threads
+    case 0: case 1: case 3: case 8: return 128;
+    case 2: return 64;
+    case 4: case 7: return 256;
+    default: return 0;
+  }
+}
+
 int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
-  T2V_CHECK_ARG(!(p.colsum && p.cs_mode != 0) || (c.tile >= W8_BASE && w8_ok(p)),
+  T2V_CHECK_ARG(!(p.colsum && p.cs_mode != 0) || colsum_bm(p, c) > 0,
                 "t2v_gemm: colsum requested but the kernel selected for this descriptor cannot emit it (ask t2v_gemm_colsum_rows first)");
   if (c.tile >= W8_BASE) {
     if (w8_ok(p)) return t2v_gemm_w8_launch(p, c.tile - W8_BASE, c.stages * 32, c.split, s);
@@ -1392,8 +1424,7 @@ extern "C" int t2v_gemm_colsum_rows(const T2VGemm* pp) {
     g_autotune = !e ? 1 : (e[0] == '0' ? 0 : ((e[0] == 'l' || e[0] == '2') ? 2 : 1));
   }
   if (g_autotune == 2) return 0;                              // tuning run: the tile is not known before the launch
-  const DmaCfg c = pick_cfg(*pp, nullptr);
-  return c.tile >= W8_BASE ? t2v_gemm_w8_bm(c.tile - W8_BASE) : 0;
+  return colsum_bm(*pp, pick_cfg(*pp, nullptr));
 }
 
 extern "C" int t2v_gemm(const T2VGemm* pp, t2v_stream_t stream) {

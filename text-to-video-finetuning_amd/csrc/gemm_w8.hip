@@ -27,7 +27,7 @@
 // LDS image, swizzle and the buffer-descriptor loader are gemm.hip's (lane-linear DMA image, XOR on source chunk + read).
 #include <stdlib.h>
 #include <type_traits>
-#include "common.h"
+#include "colsum.h"
 
 namespace {
 
@@ -533,26 +533,9 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   // the rows it writes; the RPI threads of a column chunk are combined in fixed order through LDS after the last pass
   const int Nb = p.n_split > 0 ? p.n_split : N;
   const int cs_mode = p.colsum ? p.cs_mode : 0;
-  float cs1[8], cs2[8], c_mu[8], c_rs[8], c_g[8], c_b[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) cs1[e] = cs2[e] = c_mu[e] = c_rs[e] = c_g[e] = c_b[e] = 0.f;
-  const bf16_t* CX = nullptr;
-  if (cs_mode == 2 && cact && !rankcol) {
-    CX = (const bf16_t*)p.cs_x;
-    const int cpg = Nb / p.cs_G;
-    const int dom = (int)(m0 / p.cs_domain_rows);
-    const float icnt = 1.f / ((float)p.cs_domain_rows * (float)cpg);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = col + e;
-      const float* sp = p.cs_sums + ((long long)dom * p.cs_G + c / cpg) * 2;
-      const float mu = sp[0] * icnt;
-      c_mu[e] = mu;
-      c_rs[e] = rsqrtf(fmaxf(sp[1] * icnt - mu * mu, 0.f) + p.cs_eps);
-      c_g[e] = p.cs_gamma[c];
-      c_b[e] = p.cs_beta[c];
-    }
-  }
+  CsState cst;
+  cs_init(cst, p, cs_mode, cact && !rankcol, m0, col, Nb);
+  const bf16_t* CX = (cs_mode == 2 && cact && !rankcol) ? (const bf16_t*)p.cs_x : nullptr;
   // ---- split-K hand-off (splits > 1).  The splits of a tile draw a ticket when their K loop is done; the LAST one keeps its
   // partial tile in LDS / registers and becomes the reducer, the others write theirs as fp32 rows to the caller's workspace
   // (slab [tile][z]) and then count themselves done.  The reducer waits for splits-1 done marks (those workgroups finished
@@ -700,57 +683,13 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
         const bf16x8 ov = pack8bf(v);
         *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = ov;
-        if (cs_mode == 1) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float q = bf2f((unsigned short)ov[e]);
-            cs1[e] += q;
-            cs2[e] += q * q;
-          }
-        } else if (cs_mode == 2) {                   // the two sums of gn_stats_kernel<true> (norm.hip), same arithmetic
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float xh = (bf2f((unsigned short)rv[it][e]) - c_mu[e]) * c_rs[e];
-            float dz = bf2f((unsigned short)ov[e]);
-            if (p.cs_silu) {
-              const float zz = xh * c_g[e] + c_b[e];
-              const float sg = sigmoid_f(zz);
-              dz *= sg * (1.f + zz * (1.f - sg));
-            }
-            cs1[e] += dz * c_g[e];
-            cs2[e] += dz * c_g[e] * xh;
-          }
-        }
+        if (cs_mode != 0) cs_add(cst, cs_mode, ov, rv[it], p.cs_silu);
       }
     }
   }
   if (cs_mode != 0 && role != 1) {
     __syncthreads();                                 // staging buffer free: [RPI][BN][2] partials of the column chunks
-    float* red = (float*)smem;
-    if (cact && !rankcol) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[((r0 * BN) + cc * 8 + e) * 2] = cs1[e];
-        red[((r0 * BN) + cc * 8 + e) * 2 + 1] = cs2[e];
-      }
-    }
-    __syncthreads();
-    for (int c2 = tid; c2 < BN; c2 += NT) {
-      const int gc = n0 + c2;
-      if (c2 >= ncols || gc >= Nb) continue;
-      float a0 = 0.f, a1 = 0.f;
-      for (int q = 0; q < RPI; ++q) {                // fixed order
-        a0 += red[((q * BN) + c2) * 2];
-        a1 += red[((q * BN) + c2) * 2 + 1];
-      }
-      float* o = p.colsum + 4 + ((long long)tm * Nb + gc) * 2;
-      o[0] = a0;
-      o[1] = a1;
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-      ((int*)p.colsum)[0] = BM;
-      ((int*)p.colsum)[1] = Nb;
-    }
+    cs_flush(cst, p, (float*)smem, cact && !rankcol, r0, RPI, cc, BN, tid, NT, n0, ncols, Nb, tm, BM);
   }
   if (writer) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's slab rows have left

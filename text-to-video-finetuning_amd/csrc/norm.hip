@@ -416,11 +416,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------ GroupNorm statistics from GEMM-epilogue column sums
-// grid (G, ndomains), 64 threads: thread i owns items i, i+64, .. of the (tile, column-of-group) list — a fixed assignment —
-// and the 64 partials are added in lane order: bit-reproducible.
-__global__ __launch_bounds__(64) void gn_finish_kernel(const float* __restrict__ colsum, int rows_per_domain, int C, int G,
-                                                        float* __restrict__ out) {
-  __shared__ float sred[64 * 2];
+// grid (G, ndomains), 256 threads: thread i owns items i, i+256, .. of the (tile, column-of-group) list — a fixed assignment
+// with the loads of up to 8 items in flight — and the partials are added in a fixed two-level order: bit-reproducible.
+__global__ __launch_bounds__(256) void gn_finish_kernel(const float* __restrict__ colsum, int rows_per_domain, int C, int G,
+                                                         float* __restrict__ out) {
+  __shared__ float sred[256 * 2];
   const int bmt = ((const int*)colsum)[0], nb = ((const int*)colsum)[1];
   const int g = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
@@ -429,11 +429,19 @@ __global__ __launch_bounds__(64) void gn_finish_kernel(const float* __restrict__
     const int tpd = rows_per_domain / bmt;
     const float* base = colsum + 4 + ((long long)d * tpd * nb + g * cpg) * 2;
     const int items = tpd * cpg;
-    for (int i = tid; i < items; i += 64) {
-      const int t = i / cpg, c = i - t * cpg;
-      const float* q = base + ((long long)t * nb + c) * 2;
-      a0 += q[0];
-      a1 += q[1];
+    for (int i0 = tid; i0 < items; i0 += 256 * 8) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int t = i / cpg, c = i - t * cpg;
+        v[u] = i < items ? *(const float2*)(base + ((long long)t * nb + c) * 2) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a0 += v[u].x;
+        a1 += v[u].y;
+      }
     }
   } else {
     a0 = a1 = __builtin_nanf("");                   // a caller bug must not pass silently
@@ -441,9 +449,17 @@ __global__ __launch_bounds__(64) void gn_finish_kernel(const float* __restrict__
   sred[tid * 2] = a0;
   sred[tid * 2 + 1] = a1;
   __syncthreads();
+  float seg_tot = 0.f;
+  if (tid < 32) {                                   // 16 segments x 2 moments: segment sums in index order
+    const int seg = tid >> 1, w = tid & 1;
+    for (int q = 0; q < 16; ++q) seg_tot += sred[(seg * 16 + q) * 2 + w];
+  }
+  __syncthreads();
+  if (tid < 32) sred[tid] = seg_tot;
+  __syncthreads();
   if (tid < 2) {
     float tot = 0.f;
-    for (int q = 0; q < 64; ++q) tot += sred[q * 2 + tid];
+    for (int q = 0; q < 16; ++q) tot += sred[q * 2 + tid];
     out[((long long)d * G + g) * 2 + tid] = tot;
   }
 }
@@ -496,7 +512,7 @@ extern "C" int t2v_gn_finish(const float* colsum, int ndomains, int rows_per_dom
                              t2v_stream_t stream) {
   if (int e = gn_check("t2v_gn_finish", C, G, 8)) return e;
   T2V_CHECK_ARG(colsum && sums && ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_finish: bad args");
-  T2V_LAUNCH(gn_finish_kernel, dim3(G, ndomains), dim3(64), 0, (hipStream_t)stream, colsum, rows_per_domain, C, G, sums);
+  T2V_LAUNCH(gn_finish_kernel, dim3(G, ndomains), dim3(256), 0, (hipStream_t)stream, colsum, rows_per_domain, C, G, sums);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
