@@ -137,7 +137,7 @@ int t2v_gemm_w8_configs(void);
 /* Dropout epoch.  Every dropout-capable entry point (t2v_gemm epilogue, t2v_gn_apply / t2v_gn_bwd_*, t2v_lowrank_update_drop,
  * t2v_dropout_mask) takes its seed BY VALUE, so a captured HIP graph would replay the same masks every step.  With an epoch
  * registered, the launches issued afterwards also carry the ADDRESS of this 8-byte device counter and use
- * seed + (*counter) * 0x9E3779B97F4A7C15; the caller bumps the counter once per optimisation step (inside the graph), forward
+ * seed ^ splitmix64(*counter + 0x9E3779B97F4A7C15); the caller bumps the counter once per optimisation step (inside the graph), forward
  * and backward of one step read the same value.  NULL unregisters (seeds are used as given: the protocol of oracle/dropout.py). */
 int t2v_set_dropout_epoch(const unsigned long long* device_counter);
 /* Tuned tile table: text, one line per problem signature ("M N K a_mode n_split out_mode has_res batch KH KW sy tdiv up C

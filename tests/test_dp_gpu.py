@@ -79,3 +79,104 @@ def test_two_process_dp_step_equals_single_process_two_clip_step(tmp_path):
     assert float(upd_sp.norm()) > 0 and relerr(upd_dp, upd_sp) < 1e-2      # AdamW on the mean gradient, same clip as single process
     mean = 0.5 * (float(l0) + float(l1))
     assert abs(r0["loss"] - mean) < 1e-4 * abs(mean) and abs(r1["loss"] - mean) < 1e-4 * abs(mean)
+
+
+# ---- the reference's own loop under data parallelism: `loss.backward(); optimizer.step()` with FlatAdamW doing the exchange
+def _loop_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    import parity_utils as pu
+    from t2v_amd.training import DenoiseTrainer, FlatAdamW
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        probe = torch.ones(4, device="cuda")
+        dist.all_reduce(probe)
+    except Exception as e:   # noqa: BLE001
+        torch.save(dict(unsupported=f"{type(e).__name__}: {e}"), os.path.join(out_dir, f"l{rank}.pt"))
+        dist.destroy_process_group()
+        return
+    ounet, ovae, _ = pu.build_oracle(False, 4, 0.05)
+    dunet, dvae = pu.build_native(ounet, ovae, False, 4)
+    params = [p for p in dunet.parameters() if p.requires_grad]
+    # train.py:661-667 without the DDP wrap of the UNet: the optimizer owns the exchange
+    opt = FlatAdamW(params, lr=1e-3, model=dunet)                      # world size from the default process group
+    assert opt.world == world
+    helper = DenoiseTrainer.__new__(DenoiseTrainer)                    # only its loss_fn (= finetune_unet, train.py:720-836)
+    helper.__dict__.update(unet=dunet, vae=dvae, text_encoder=None, _aux_stream=None, batch_passes=True, use_offset_noise=False,
+                           offset_noise_strength=0.1, cache_latents=False)
+    from t2v_amd.schedulers import DDPMScheduler
+    helper.scheduler = DDPMScheduler()
+    losses = []
+    for _ in range(2):                                                 # two optimisation steps of the reference's loop
+        loss = helper.loss_fn(_batch(rank))
+        loss.backward()
+        opt.note_loss(loss)
+        opt.step()
+        losses.append(float(opt.last_mean_loss))
+        opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    torch.save(dict(losses=losses, flat_p=opt.flat_p.cpu()), os.path.join(out_dir, f"l{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_style_loop_under_dp_keeps_replicas_in_lock_step(tmp_path):
+    """`loss.backward(); optimizer.step(); optimizer.zero_grad(set_to_none=True)` on two ranks with FlatAdamW performing the
+    flat all-reduce itself: replicas stay bit-equal, the logged loss is the rank mean, and the parameters equal what the
+    trainer's own DP path (`DenoiseTrainer.train_step`, same clips) produces."""
+    import socket
+    import torch.multiprocessing as mp
+    from conftest import relerr
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"l{r}.pt") for r in (0, 1))
+    if "unsupported" in r0:
+        pytest.skip(f"gloo cannot all-reduce device tensors in this build: {r0['unsupported']}")
+    assert torch.equal(r0["flat_p"], r1["flat_p"])
+    assert r0["losses"] == r1["losses"] and all(l > 0 for l in r0["losses"])
+    # single process reference: two clips accumulated, AdamW on the mean, twice
+    tr = _build_trainer(1)
+    for _ in range(2):
+        tr.opt.zero_grad()
+        tr._fwd_bwd(_batch(0))
+        tr._fwd_bwd(_batch(1))
+        tr.opt.step(grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert relerr(r0["flat_p"], tr.opt.flat_p.cpu()) < 1e-5
+
+
+def test_rccl_allreduce_of_the_flat_gradient_buffer_around_a_graph_replay():
+    """backend="nccl" (= RCCL) at world size 1 on the real device: the collective the 8-GPU run issues every step, on the very
+    buffer (`flat_g_full`, loss in the tail slot), before and after a HIP-graph replay of the step."""
+    import socket
+    import torch.distributed as dist
+    from t2v_amd.parallel import allreduce_flat_grads
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        tr = _build_trainer(1)
+        batch = _batch(0)
+        tr.capture(batch, warmup=1)
+        l0 = tr.replay_step()
+        torch.cuda.synchronize()
+        tr.opt.zero_grad()
+        tr._graph.replay()
+        g_before = tr.opt.flat_g.clone()
+        scale, mean = allreduce_flat_grads(tr.opt.flat_g_full, 1, None, loss=tr._static_loss, tail=tr.opt.numel, always=True)
+        torch.cuda.synchronize()
+        assert scale == 1.0 and torch.equal(tr.opt.flat_g, g_before) and float(g_before.norm()) > 0
+        assert abs(float(mean) - float(tr._static_loss)) < 1e-6 * abs(float(tr._static_loss))
+        tr.opt.step(grad_scale=scale, refresh=False)
+        l1 = tr.replay_step()                       # and the graph still replays after the collective touched its buffers
+        torch.cuda.synchronize()
+        assert torch.isfinite(l1) and float(l0) > 0
+    finally:
+        dist.destroy_process_group()

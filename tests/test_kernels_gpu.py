@@ -421,7 +421,7 @@ def test_dropout_mask_protocol_matches_cpu_restatement():
 
 
 def test_dropout_epoch_offsets_every_dropout_kernel_like_the_restatement():
-    """t2v_set_dropout_epoch: launches issued while a device counter is registered use seed + counter * 0x9E3779B97F4A7C15 — the
+    """t2v_set_dropout_epoch: launches issued while a device counter is registered use seed ^ splitmix64(counter + G) — the
     counter is read when the kernel RUNS (a captured graph sees its current value) — for the mask kernel, the GroupNorm epilogue
     and the GEMM epilogue; unregistering restores the plain protocol."""
     import t2v_amd.functional as F
@@ -811,7 +811,7 @@ def test_fused_lora_dropout_matches_the_unfused_masked_path(kind):
     opt.zero_grad()
     ya.backward(dy); yb.backward(dy)
     torch.cuda.synchronize()
-    assert float((ya.float() - (yb.float())).abs().max()) > 0 or True
+    assert float(ya.float().abs().max()) > 0 and torch.isfinite(ya.float()).all()
     assert relerr(ya, yb) < 1e-2
     # the LoRA branch really is masked: ~10 % of the branch outputs are dropped
     assert relerr(xa.grad, xb.grad) < 2e-2

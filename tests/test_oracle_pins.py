@@ -207,3 +207,24 @@ def test_ms_webui_key_remap_matches_reference_converter():
     ld = SL.lora_state_dict(unet)
     lout = convert_unet_state_dict(ld, strict_mapping=True)
     assert {k: [nk, list(lout[nk].shape)] for k, nk in zip(ld.keys(), lout.keys())} == gold["stable_lora"]
+
+
+def test_dropout_masks_of_consecutive_epochs_are_not_shifted_copies():
+    """The epoch is hashed before it meets the seed (csrc/common.h eff_seed, oracle/dropout.effective_seed): with the first
+    protocol (seed + epoch * G on the index lattice) the mask of step e+1 was the mask of step e shifted by one flat element.
+    Consecutive epochs must agree with each other — under every small shift — only at the chance rate."""
+    import torch
+    from oracle.dropout import effective_seed, keep_mask
+    rows, cols, p, seed = 64, 256, 0.3, 0x5EED1234
+    n = rows * cols
+    chance = p * p + (1 - p) * (1 - p)                       # P(two independent masks agree) = 0.58
+    for e in (1, 2, (1 << 32) + 7):
+        a = keep_mask(effective_seed(seed, e), rows, cols, p).flatten()
+        b = keep_mask(effective_seed(seed, e + 1), rows, cols, p).flatten()
+        assert abs(float(a.float().mean()) - (1 - p)) < 0.02
+        for shift in range(-3, 4):
+            lo, hi = max(0, shift), min(n, n + shift)
+            agree = float((a[lo:hi] == b[lo - shift:hi - shift]).float().mean())
+            assert abs(agree - chance) < 0.03, (e, shift, agree)
+    # and different seeds under one epoch stay distinct masks
+    assert not torch.equal(keep_mask(effective_seed(1, 5), 8, 64, p), keep_mask(effective_seed(2, 5), 8, 64, p))

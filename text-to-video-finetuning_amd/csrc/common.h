@@ -38,8 +38,15 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf
 // reach the kernels by value, so a captured HIP graph would replay the same masks every step; with the epoch the captured
 // launches carry the counter's ADDRESS and the step bumps its value (forward and backward of one step read the same value).
 extern const unsigned long long* t2v_drop_epoch;      // host-side: what the next launches pass to their kernels (may be null)
+// The epoch goes THROUGH the hash before it meets the seed: drop_keep() walks the element index along the lattice
+// seed + (idx+1)*G, so adding epoch*G (round 2) made the mask of step e+1 the mask of step e shifted by one element.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
 __device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, const unsigned long long* epoch) {
-  return epoch ? seed + *epoch * 0x9E3779B97F4A7C15ull : seed;
+  return epoch ? seed ^ mix64(*epoch + 0x9E3779B97F4A7C15ull) : seed;
 }
 
 // counter-based dropout keep decision: splitmix64 of (seed, element index)

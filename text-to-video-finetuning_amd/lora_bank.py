@@ -21,6 +21,8 @@ import torch
 
 from .functional import ceil8
 
+MERGE_MAX_RANK = 32      # padded rank window of csrc/lora_merge.hip (RMAX)
+
 
 class LoraEntry:
     __slots__ = ("r", "rp", "n", "npad", "cin", "cin_p", "taps", "down_off", "up_off", "down_numel", "up_numel",
@@ -234,6 +236,10 @@ class MergePlan:
             if id(e) in seen or not all(hasattr(e, a) for a in ("down_off", "up_off")):
                 continue
             seen.add(id(e))
+            if e.rp > MERGE_MAX_RANK:
+                # beyond the merge kernel's rank window: the layer keeps its LoRA branch apart (leaves.run_layer falls back to
+                # functional.lora_layer / the GEMM composition because `merge_scale` stays unset) — any rank the reference accepts
+                continue
             entries.append((e, mod))
         self.entries = entries
         self._keep = []
@@ -243,8 +249,9 @@ class MergePlan:
             base = _wrapper_parts(mod)[0]
             w32 = _prep_compute(base.weight, "fwd32", None)
             K = e.taps * e.cin_p
-            if tuple(w32.shape) != (e.npad, K) or e.rp > 32:
-                raise RuntimeError("t2v_amd: LoRA merge plan: unexpected weight geometry")
+            if tuple(w32.shape) != (e.npad, K):
+                raise RuntimeError(f"t2v_amd: LoRA merge plan: prepared base weight {tuple(w32.shape)} does not match the bank "
+                                   f"entry ({e.npad}, {K})")
             g = e.group
             if g is not None:
                 if id(g) not in groups_done:
@@ -285,9 +292,19 @@ class MergePlan:
             self.tile_job_dev = torch.frombuffer(bytearray(bytes(tile_job)), dtype=torch.int32).to(dev)
         self.bytes = sum(w.numel() * 4 for w in self._keep) + sum(e.weff_fwd.numel() * 4 for e, _ in entries)
 
+    def wanted(self):
+        """True if some wrapped layer can take the merged path right now: wrappers whose dropout is active (the reference's
+        default train mode, utils/lora.py:35,89) evaluate the branch apart and never read W_eff — refreshing it would be 15 GB
+        of HBM traffic per step for nothing."""
+        for _, mod in self.entries:
+            d = getattr(mod, "dropout", None)
+            if not (isinstance(d, torch.nn.Dropout) and d.training and d.p > 0.0):
+                return True
+        return False
+
     def run(self):
         """Refresh every W_eff from the current fp32 factors (asynchronous on the current stream; graph-capture safe)."""
-        if self.njobs:
+        if self.njobs and self.wanted():
             from . import native as nv
             nv.call("t2v_lora_merge", self.jobs_dev.data_ptr(), self.njobs, self.tile_job_dev.data_ptr(), self.ntiles, nv.stream())
 

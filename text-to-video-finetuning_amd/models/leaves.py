@@ -54,16 +54,39 @@ class _Out(SimpleNamespace):
     pass
 
 
-_seed_state = {"base": 0x5EED, "ctr": 0}
+_seed_state = {"base": 0x5EED, "ctr": 0, "step": 0}
 
 
 def set_dropout_seed(seed):
-    _seed_state["base"], _seed_state["ctr"] = int(seed), 0
+    _seed_state["base"], _seed_state["ctr"], _seed_state["step"] = int(seed), 0, 0
 
 
 def _next_seed():
     _seed_state["ctr"] += 1
     return (_seed_state["base"] * 1000003 + _seed_state["ctr"]) & 0xFFFFFFFFFFFF
+
+
+def assign_dropout_names(root):
+    """Give every module of `root` its qualified name as the key of its dropout seed (the trainers call this after LoRA
+    injection).  A site's seed is then a function of (base seed, module name, optimisation step) instead of the order in which
+    the forward happens to reach it: a recompute (gradient checkpointing) draws the same mask without rewinding a counter, and
+    the CPU oracle can restate the masks site by site whatever order ITS forward visits them in (oracle/dropout.py)."""
+    for name, m in root.named_modules():
+        m.__dict__["_t2v_name"] = name
+
+
+def advance_dropout_step():
+    """Next optimisation step: new masks for plain eager loops (the trainer's captured step moves the DEVICE epoch instead)."""
+    _seed_state["step"] += 1
+
+
+def _seed_for(mod, suffix=""):
+    name = mod.__dict__.get("_t2v_name")
+    if name is None:
+        return _next_seed()               # stand-alone module (kernel tests): counter protocol
+    import zlib
+    key = zlib.crc32((name + suffix).encode())
+    return (_seed_state["base"] * 1000003 + key * 97 + _seed_state["step"] * 7919) & 0xFFFFFFFFFFFF
 
 
 def _drop_p(mod):
@@ -91,7 +114,7 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
             if p == 0.0 or entry.rp in (8, 16, 24, 32, 48, 64, 96):
                 # LoRA branch kept apart from the weight: active dropout (the reference's default train mode), or merge off
                 return F.lora_layer(x, base.weight, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry,
-                                    float(mod.scale), rowbias, residual, drop_p=p, drop_seed=_next_seed() if p > 0 else 0)
+                                    float(mod.scale), rowbias, residual, drop_p=p, drop_seed=_seed_for(mod) if p > 0 else 0)
         y = F.conv_linear(x, base.weight, base.bias, cfg, rowbias, residual)
         t = F.conv_linear(x, mod.lora_down.weight, None, cfg)
         sel = getattr(mod, "selector", None)
@@ -99,7 +122,7 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
             t = F.conv_linear(t, sel.weight, None, LINEAR)
         p = _drop_p(getattr(mod, "dropout", None))
         return F.conv_linear(t, mod.lora_up.weight, None, LINEAR, None, y, alpha=float(mod.scale), drop_p=p,
-                             drop_seed=_next_seed() if p > 0 else 0)
+                             drop_seed=_seed_for(mod) if p > 0 else 0)
     if hasattr(mod, "lora_A") and hasattr(mod, "lora_B"):                               # loralib / stable_lora style
         w = mod.weight
         merged = bool(getattr(mod, "merged", False))
@@ -113,7 +136,7 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
             # loralib Linear with an active lora_dropout: x W^T + (drop(x) A^T B^T) * scaling — the dropout sits on the INPUT of
             # the low-rank branch, so the branch cannot be folded into the weight (the conv flavours have no dropout in forward)
             y = F.conv_linear(x, w, mod.bias, cfg, rowbias, residual)
-            t = F.conv_linear(F.dropout(x, p, _next_seed()), mod.lora_A, None, LINEAR)
+            t = F.conv_linear(F.dropout(x, p, _seed_for(mod, ".lora_dropout")), mod.lora_A, None, LINEAR)
             return F.conv_linear(t, mod.lora_B, None, LINEAR, None, y, alpha=float(mod.scaling))
         if getattr(mod, "r", 0) > 0 and not getattr(mod, "merged", False):
             delta = (mod.lora_B @ mod.lora_A)
@@ -200,7 +223,7 @@ class ResnetBlock2D(nn.Module):
             rb = run_layer(self.time_emb_proj, temb.act)          # [B, Cout]; broadcast over the B's F*h*w rows
         h = run_layer(self.conv1, a, cfg3, rowbias=rb, colsum=True)
         a2 = F.group_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, x.n,
-                          _drop_p(self.dropout), _next_seed() if _drop_p(self.dropout) > 0 else 0)
+                          _drop_p(self.dropout), _seed_for(self, ".dropout") if _drop_p(self.dropout) > 0 else 0)
         sc = xr
         if self.conv_shortcut is not None:
             sc = run_layer(self.conv_shortcut, xr, ConvCfg.conv2d(x.n, x.h, x.w, 1, 1, 0))
@@ -234,9 +257,10 @@ class TemporalConvLayer(nn.Module):
             gn, conv = seq[0], seq[-1]
             p = max((_drop_p(mm) for mm in seq), default=0.0)
             if i == 0:       # xr: the identity branch's use of x (gradient summed inside the first norm's backward kernel)
-                a, xr = F.group_norm_res(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
+                a, xr = F.group_norm_res(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p,
+                                          _seed_for(self, f".conv{i + 1}") if p > 0 else 0)
             else:
-                a = F.group_norm(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _next_seed() if p > 0 else 0)
+                a = F.group_norm(cur, gn.weight, gn.bias, gn.num_groups, gn.eps, True, B, p, _seed_for(self, f".conv{i + 1}") if p > 0 else 0)
             cur = run_layer(conv, a, cfg, residual=xr if i == 3 else None, colsum=True)
         return Tok(cur, x.n, x.h, x.w)
 

@@ -31,12 +31,12 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def allreduce_flat_grads(flat_g, world, group=None, loss=None, tail=None):
+def allreduce_flat_grads(flat_g, world, group=None, loss=None, tail=None, always=False):
     """SUM-all-reduce the flat gradient buffer; returns (grad_scale, mean_loss_or_None), grad_scale = 1/world being applied
     by the optimizer kernel.  `tail`: index of a spare slot INSIDE `flat_g` (behind the gradients) that carries the loss
     through the same collective — no concatenation copy, no second collective (the reference all_gathers the loss per
     micro-step, train.py:856).  Without `tail` the loss is appended to a copy of the buffer (helper form)."""
-    if world <= 1:
+    if world <= 1 and not (always and dist.is_initialized()):      # `always`: run the collective at world size 1 too (tests)
         return 1.0, loss
     if loss is None:
         dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=group)

@@ -51,8 +51,20 @@ class FlatAdamW:
     cloneofsimo-style wrappers are stored in GEMM layout (lora_bank.py) and a bf16 shadow `flat_p16` is kept, refreshed by
     `refresh_bf16()` (one cast kernel per step)."""
 
-    def __init__(self, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0, model=None):
+    def __init__(self, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0, model=None,
+                 process_group=None, world_size=None):
+        """`process_group` / `world_size`: data parallelism under a plain `loss.backward(); optimizer.step()` loop (the
+        reference's, train.py:848-879).  The LoRA factor gradients are written straight into the flat buffer by side kernels —
+        they never pass through autograd hooks, so a DistributedDataParallel wrapper (what `accelerator.prepare(unet)` builds,
+        train.py:661-667) would not reduce them.  With world_size > 1 `step()` therefore performs the exchange itself: ONE
+        all-reduce(SUM) of the flat gradient buffer (whose tail slot carries the loss handed to `note_loss`), then clip + AdamW on
+        the mean.  world_size=None: taken from the initialised default process group (1 if there is none)."""
         from . import lora_bank
+        if world_size is None:
+            import torch.distributed as dist
+            world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.pg, self.world = process_group, int(world_size)
+        self.last_mean_loss = None
         seen, plist = set(), []
         for p in params:
             if id(p) not in seen and p.requires_grad:
@@ -65,6 +77,9 @@ class FlatAdamW:
             raise RuntimeError("FlatAdamW runs on a ROCm device only")
         self.params = plist
         self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
+        if model is not None:
+            from .models.leaves import assign_dropout_names
+            assign_dropout_names(model)          # dropout seeds keyed by module name (models/leaves.py)
         plans = lora_bank.plan(model)
         plist = lora_bank.reorder(plist, plans)
         self.params = plist
@@ -133,13 +148,24 @@ class FlatAdamW:
     def grad_norm(self):
         return self.sumsq.sqrt()
 
-    def step(self, grad_scale=1.0, refresh=True):
-        """clip + AdamW on the flat buffers (2 kernels).  `refresh`: re-derive the bf16 copies of the LoRA factors right away,
-        so that a plain `loss.backward(); optimizer.step()` loop (the reference's) needs no extra call; DenoiseTrainer
-        refreshes inside its captured step instead."""
+    def note_loss(self, loss):
+        """Put this rank's loss into the tail slot of the flat gradient buffer: the next `step()` all-reduces it together with
+        the gradients and leaves the rank mean in `last_mean_loss` (the reference gathers the loss with its own collective per
+        micro-step, train.py:856)."""
+        self.flat_g_full[self.numel] = loss.detach().to(self.flat_g_full.dtype)
+
+    def step(self, grad_scale=1.0, refresh=True, exchange=True):
+        """(all-reduce when world_size > 1) + clip + AdamW on the flat buffers (2 kernels).  `refresh`: re-derive the bf16 copies
+        of the LoRA factors right away, so that a plain `loss.backward(); optimizer.step()` loop (the reference's) needs no extra
+        call; DenoiseTrainer refreshes inside its captured step instead (and exchanges itself: exchange=False)."""
         from .functional import join_side_stream
         join_side_stream()                 # no-op after a normal backward (its end-of-backward callback already joined)
         self._ensure_homed()
+        if exchange and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_g_full, op=dist.ReduceOp.SUM, group=self.pg)
+            grad_scale = grad_scale / self.world
+            self.last_mean_loss = self.flat_g_full[self.numel] / self.world
         s = nv.stream()
         self.sumsq.zero_()
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
@@ -149,6 +175,8 @@ class FlatAdamW:
                 self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 self.sumsq.data_ptr() if clip else None, float(self.max_grad_norm or 0.0), float(grad_scale),
                 self.step_count.data_ptr(), s)
+        from .models.leaves import advance_dropout_step
+        advance_dropout_step()
         if refresh:
             self.refresh_bf16()
 
@@ -170,7 +198,7 @@ class DenoiseTrainer:
         self.scheduler = scheduler or DDPMScheduler()
         if rescale_schedule:
             self.scheduler.rescale_betas()         # train.py:689-690 (betas only; see schedulers.enforce_zero_terminal_snr)
-        self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet)
+        self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet, world_size=1)   # (exchange: below)
         self.pg, self.world = process_group, world_size
         self.rank = 0
         if world_size > 1:
