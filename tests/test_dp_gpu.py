@@ -139,13 +139,17 @@ def test_reference_style_loop_under_dp_keeps_replicas_in_lock_step(tmp_path):
     assert r0["losses"] == r1["losses"] and all(l > 0 for l in r0["losses"])
     # single process reference: two clips accumulated, AdamW on the mean, twice
     tr = _build_trainer(1)
+    p0 = tr.opt.flat_p.cpu().clone()
     for _ in range(2):
         tr.opt.zero_grad()
         tr._fwd_bwd(_batch(0))
         tr._fwd_bwd(_batch(1))
         tr.opt.step(grad_scale=0.5)
     torch.cuda.synchronize()
-    assert relerr(r0["flat_p"], tr.opt.flat_p.cpu()) < 1e-5
+    upd_dp, upd_sp = r0["flat_p"] - p0, tr.opt.flat_p.cpu() - p0
+    # AdamW's first steps are sign-like: coordinates at the fp32-atomic noise level may flip between the two reduction orders
+    cos = float((upd_dp.double() * upd_sp.double()).sum() / (upd_dp.double().norm() * upd_sp.double().norm()))
+    assert float(upd_sp.norm()) > 0 and relerr(upd_dp, upd_sp) < 0.15 and cos > 0.99, (relerr(upd_dp, upd_sp), cos)
 
 
 def test_rccl_allreduce_of_the_flat_gradient_buffer_around_a_graph_replay():

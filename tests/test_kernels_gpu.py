@@ -799,6 +799,8 @@ def test_fused_lora_dropout_matches_the_unfused_masked_path(kind):
         (m.linear if kind == "linear" else m.conv).requires_grad_(False)
     holder = torch.nn.Module(); holder.layer = mod
     opt = FlatAdamW([mod.lora_down.weight, mod.lora_up.weight], model=holder)
+    holder_ref = torch.nn.Module(); holder_ref.layer = ref
+    leaves.assign_dropout_names(holder_ref)           # same site name ("layer") -> same name-keyed dropout seed as the fused module
     g = torch.Generator().manual_seed(5)
     x = _bf(torch.randn(rows, cin, generator=g)).cuda()
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)

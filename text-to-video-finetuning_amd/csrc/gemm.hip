@@ -1020,10 +1020,17 @@ int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
   }
   T2VGemm q = p;
   int split = c.split;
+  // the first 64 KB of the caller's scratch belong to the arrival counters of the 8-wave kernels' in-launch split-K (they must
+  // stay zero between launches): this path's partial slices live behind them
+  constexpr size_t WS_RESERVED = 65536;
   // a cached / pinned configuration may ask for split-K while THIS launch brings no (or too small a) scratch buffer
-  if (split > 1 && (!p.workspace || p.batch > 1 || p.out_mode != T2V_OUT_BF16 ||
-                    (size_t)p.M * p.N * 4 * (size_t)split + 16 > p.workspace_bytes))
+  if (split > 1 && (!p.workspace || p.batch > 1 || p.out_mode != T2V_OUT_BF16 || p.workspace_bytes <= WS_RESERVED ||
+                    (size_t)p.M * p.N * 4 * (size_t)split + 16 > p.workspace_bytes - WS_RESERVED))
     split = 1;
+  if (split > 1) {
+    q.workspace = (unsigned char*)p.workspace + WS_RESERVED;
+    q.workspace_bytes = p.workspace_bytes - WS_RESERVED;
+  }
   if (split > 1) {
     const int per = ((p.K + split - 1) / split + BK - 1) / BK * BK;
     split = (p.K + per - 1) / per;              // every split slice is written (no empty K ranges)
@@ -1078,7 +1085,7 @@ DmaCfg heuristic_cfg(const T2VGemm& p) {
     if (p.N <= 32) { bm = 128; bn = 32; }
     long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
     long long split = std::min<long long>(std::min<long long>(384 / std::max<long long>(1, tiles), p.K / 256), 32);
-    split = std::min<long long>(split, (long long)(p.workspace_bytes / ((size_t)p.M * p.N * 4 + 16)));
+    split = std::min<long long>(split, (long long)((p.workspace_bytes > 65536 ? p.workspace_bytes - 65536 : 0) / ((size_t)p.M * p.N * 4 + 16)));
     if (tiles <= 96 && split >= 2) return DmaCfg{p.N <= 32 ? 3 : 2, 0, (int)split};
   }
   if (p.N <= 32) return DmaCfg{3, shortk ? 2 : 0, 1};
@@ -1169,7 +1176,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
       if (can_split && st == 0) {
         for (int sp : {2, 4, 8, 16}) {
           if (p.K / sp < 256 || tiles * sp > 2048) continue;
-          if ((size_t)p.M * p.N * 4 * sp + 16 > p.workspace_bytes) continue;
+          if ((size_t)p.M * p.N * 4 * sp + 16 + 65536 > p.workspace_bytes) continue;
           cand.push_back(DmaCfg{t, st, sp});
         }
       }

@@ -114,8 +114,8 @@ def plan(model, fuse_groups=True):
             g.n = len(ws)
             e0 = g.entries[0]
             g.rp_each, g.rp, g.npad_each, g.npad, g.cin_p = e0.rp, e0.rp * g.n, e0.npad, e0.npad * g.n, e0.cin_p
-            if g.rp > 96:
-                continue
+            if g.rp > 96 or e0.rp > 32:          # (the streaming factor-gradient kernel takes padded ranks up to 32: wider members
+                continue                          #  run one by one, functional._lora_side_grads has the K-major GEMM fallback)
             for i, e in enumerate(g.entries):
                 e.group, e.gidx = g, i
                 e.up_numel = e.rp * g.npad            # the member's slot is a full row block of the group's up matrix
@@ -302,9 +302,29 @@ class MergePlan:
                 return True
         return False
 
+    def _mark(self, current):
+        """W_eff valid / stale: a stale merged weight switches the layers to the branch-apart path (leaves.run_layer compares
+        `merge_scale` with the wrapper's scale), so skipping a refresh can never feed stale weights to a forward."""
+        if current == getattr(self, "_current", None):
+            return
+        self._current = current
+        groups = {}
+        for e, mod in self.entries:
+            e.merge_scale = float(mod.scale) if current else None
+            if e.group is not None:
+                groups[id(e.group)] = e.group
+        for g in groups.values():
+            g.merge_scale = float(g.mods[0].scale) if current else None
+
     def run(self):
         """Refresh every W_eff from the current fp32 factors (asynchronous on the current stream; graph-capture safe)."""
-        if self.njobs and self.wanted():
+        if not self.njobs:
+            return
+        if not self.wanted():
+            self._mark(False)
+            return
+        self._mark(True)
+        if True:
             from . import native as nv
             nv.call("t2v_lora_merge", self.jobs_dev.data_ptr(), self.njobs, self.tile_job_dev.data_ptr(), self.ntiles, nv.stream())
 
