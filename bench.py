@@ -46,8 +46,8 @@ HBM_PEAK_GBS = 8000.0            # HBM3E peak, same guide
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,6 +58,9 @@ def parse():
                          "dropout 0.1 (models/unet_3d_blocks.py:312) instead of its eval_train mode; eager launches")
     ap.add_argument("--grad-checkpointing", action="store_true", help="train.py:127-129,670-675")
     ap.add_argument("--no-text-encoder", action="store_true", help="feed synthetic text states instead of running CLIP")
+    ap.add_argument("--no-default-mode", action="store_true",
+                    help="skip the extra short run in the reference's default train mode (dropout on) that fills "
+                         "config.default_mode_ms_per_step")
     ap.add_argument("--export-tune-table", default=None,
                     help="write the GEMM tile table after the run (use with T2V_GEMM_AUTOTUNE=live; scripts/tune_gemm_table.sh)")
     return ap.parse_args()
@@ -201,6 +204,8 @@ def gemm_roofline(trainer, batch):
         taps_ = (geom.KH * geom.KW) if geom is not None else 1
         abytes = (kw["M"] * (kw["K"] // taps_) + kw["M"] * kw["N"] + kw["N"] * kw["K"]) * 2.0 * z
         records.append((flops, s, e, nn_kernel, abytes, inner))
+        if tflag["attn"] > 0:                   # (module forward only: the flag is down while autograd runs the backward)
+            tunit["gemm"].append((s, e, inner))
         rc = (kw["N"] - kw["n_split"]) if kw.get("n_split", 0) > 0 else 0
         gtag = "lin" if geom is None else f"conv{geom.KH}x{geom.KW}s{geom.sy}d{geom.tdiv}u{geom.up}"
         shapes.append(((kw["M"], kw["N"] - rc, rc, kw["K"], z, gtag, "nn" if nn_kernel else "tn",
@@ -221,6 +226,31 @@ def gemm_roofline(trainer, batch):
         records.append((2.0 * (kw_a["M"] * kw_a["N"] * kw_a["K"] + kw_b["M"] * kw_b["N"] * kw_b["K"]), s, e, False, 0.0, None))
 
     conv3d, attn, wgrad, shapes, norms = [], [], [], [], []
+    # SURVEY 8(d)'s fused temporal-attention unit LN -> QKV -> softmax(FxF) -> PV -> out-proj (+residual): its launches are
+    # tagged while a TransformerTemporalModel's Attention module is running its FORWARD
+    import t2v_amd.models.leaves as _leaves
+    tflag = {"temporal": 0, "attn": 0}
+    tunit = {"flops": 0.0, "gemm": [], "core": [], "ln": [], "calls": 0}
+    _tt_fwd, _at_fwd = _leaves.TransformerTemporalModel.forward, _leaves.Attention.forward
+
+    def tt_forward(self, x, *a, **k):
+        tflag["temporal"] += 1
+        tflag["frames"] = k.get("num_frames", 1)
+        try:
+            return _tt_fwd(self, x, *a, **k)
+        finally:
+            tflag["temporal"] -= 1
+
+    def at_forward(self, x, *a, **k):
+        if tflag["temporal"] and torch.is_grad_enabled():
+            T, Cc = x.shape[0], self.heads * self.dim_head
+            tunit["flops"] += 8.0 * Cc * x.shape[1] * T + 4.0 * T * tflag.get("frames", 1) * Cc
+            tunit["calls"] += 1
+        tflag["attn"] += 1 if tflag["temporal"] else 0
+        try:
+            return _at_fwd(self, x, *a, **k)
+        finally:
+            tflag["attn"] -= 1 if tflag["temporal"] else 0
     wgrad_layers = [0]
     nv = F.nv
     orig_call = nv.call
@@ -249,6 +279,8 @@ def gemm_roofline(trainer, batch):
                 # backward reads x and dy once and writes dx (+ reads the residual gradient it absorbs)
                 alg = {"t2v_gn_stats": 0, "t2v_gn_apply": 2, "t2v_gn_bwd_stats": 0, "t2v_gn_bwd_apply": 3 + (1 if addend else 0)}[name] * E * 2
             norms.append((kind, alg, moved, s, e, inner))
+            if name == "t2v_layernorm_fwd" and tflag["temporal"] > 0:
+                tunit["ln"].append((s, e, inner))
             return r
         if name == "t2v_lora_wgrad_batch":      # a[0] = array of descriptors, a[1] = their number: one launch for all of them
             fl = by = 0.0
@@ -272,11 +304,16 @@ def gemm_roofline(trainer, batch):
         nbytes = bh * (2 * d.Sq + 2 * d.Sk) * 2.0 * (1.0 if fwd else 2.0)   # q,k,v,o (+ do,dq,dk,dv)
         kind = "text_cross" if d.Sk == 77 else ("temporal" if d.Sq == d.Sk and d.Sq <= 64 else "spatial")
         attn.append((kind, flops, nbytes, s, e, inner))
+        if fwd and tflag["attn"] > 0:
+            tunit["core"].append((s, e, inner))
         return r
 
+    _in_forward = [True]
     F.launch_gemm = timed
     F.launch_gemm_pair = timed_pair
     nv.call = timed_call
+    _leaves.TransformerTemporalModel.forward = tt_forward
+    _leaves.Attention.forward = at_forward
     side_was = F._side["enabled"]
     F._side["enabled"] = False        # one stream for the instrumented pass: an event pair on the side stream would also count
     try:                              # the time its kernel waits for the main stream's kernels to leave the CUs
@@ -288,6 +325,8 @@ def gemm_roofline(trainer, batch):
         F.launch_gemm = orig
         F.launch_gemm_pair = orig_pair
         nv.call = orig_call
+        _leaves.TransformerTemporalModel.forward = _tt_fwd
+        _leaves.Attention.forward = _at_fwd
     out = {}
     def kernel_ms(r):
         return dur(r[1], r[2], r[5])
@@ -330,6 +369,18 @@ def gemm_roofline(trainer, batch):
                 "launches": len(rs), "ms_per_step": round(ms, 3), "algorithmic_GB_per_step": round(alg / 1e9, 3),
                 "GB/s": round(alg / ms / 1e6, 1), "frac_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
                 "moved_GB_per_step": round(moved / 1e9, 3), "moved_GB/s": round(moved / ms / 1e6, 1)}
+    if tunit["calls"]:
+        # two of the three LayerNorms of a temporal BasicTransformerBlock precede an attention (norm1, norm2)
+        t_ms = (sum(dur(*r) for r in tunit["gemm"]) + sum(dur(*r) for r in tunit["core"]) + sum(dur(*r) for r in tunit["ln"]) * 2.0 / 3.0)
+        ns["temporal_block_fused_unit"] = {
+            "what": "SURVEY 8(d) fused unit (8 C^2 T + 4 T F C) / sum t over the forward launches of every temporal attention "
+                    "(LayerNorm, QKV projection, FxF attention core, output projection + residual); the unit is not ONE kernel here",
+            "units": tunit["calls"], "launches": len(tunit["gemm"]) + len(tunit["core"]) + int(len(tunit["ln"]) * 2 / 3),
+            "ms_per_step": round(t_ms, 3), "ms_projections": round(sum(dur(*r) for r in tunit["gemm"]), 3),
+            "ms_attention_core": round(sum(dur(*r) for r in tunit["core"]), 3),
+            "ms_layernorm": round(sum(dur(*r) for r in tunit["ln"]) * 2.0 / 3.0, 3), "GFLOP_per_step": round(tunit["flops"] / 1e9, 1),
+            "TFLOP/s": round(tunit["flops"] / t_ms / 1e9, 1),
+            "frac_mfma_peak": round(tunit["flops"] / t_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
     out["north_star"] = ns
     if os.environ.get("T2V_BENCH_SHAPE_TABLE"):      # per-problem-signature GEMM time of one step (diagnostic)
         agg = {}
@@ -409,7 +460,9 @@ def cpu_baseline(steps, device):
     unet.requires_grad_(False)
     vae.requires_grad_(False)
     inject_trainable_lora_extended(unet, {"UNet3DConditionModel"}, r=r)
-    for m in unet.modules():
+    from oracle.weights import randomize_lora_up
+    randomize_lora_up(unet, scale=0.02)          # lora_up ~ N(0, 0.02^2): at the reference's init (up = 0) every LoRA branch is
+    for m in unet.modules():                     # arithmetically inert and the in-run check would only see the frozen path
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     unet.train()
@@ -463,8 +516,9 @@ def cpu_baseline(steps, device):
                        f"{cores} threads, temporal Conv3d run as conv2d) after one warm-up step: {med:.2f} s/step "
                        f"(all: {', '.join(f'{t:.1f}' for t in times)}); a C1 clip is ~1/8 of the C2 clip's work",
                 eps_mse_rel_err=rel, eps_mse_cpu=l_cpu, eps_mse_gpu=l_gpu,
-                eps_mse_note="same seeded ModelScope-1.7B weights and C1 batch: native trainer loss on the GPU vs the CPU fp32 oracle, "
-                             "this run; the C2-size check (3.9e-5) is tests/test_lora_grads_gpu.py against the committed oracle fixture")
+                eps_mse_note="same seeded ModelScope-1.7B weights (lora_up ~ N(0, 0.02^2): live LoRA branches) and C1 batch: native "
+                             "trainer loss on the GPU vs the CPU fp32 oracle, this run; full-size C1/C2 loss + every factor gradient "
+                             "against committed oracle fixtures: tests/test_lora_grads_gpu.py")
 
 
 def _self_spawn(args):
@@ -549,11 +603,44 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    # host time to ISSUE one step (zero_grad, graph launch, exchange, clip + AdamW launches) with the device idle: what bounds
+    # the step rate at N > 1 once the device work shrinks (a replay of a still-running graph blocks the host, so the loop above
+    # cannot show it); median of 5
+    hs = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss = step()
+        hs.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    host_ms = round(sorted(hs)[2] * 1e3, 3)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     final_loss = float(loss.item())
+
+    default_mode_ms = None
+    if (rank == 0 and world == 1 and args.config == "c2" and not args.dropout and not args.no_default_mode and use_graph):
+        # the reference's DEFAULT train mode (LoRA dropout 0.1, utils/lora.py:35,89; TemporalConvLayer dropout 0.1,
+        # models/unet_3d_blocks.py:312) on the same clip: a short graph-replayed run beside the headline (eval_train) line
+        try:
+            d_unet, d_vae, d_train = build_models(frames, r, dev, seed=0, dropout=True, grad_ckpt=args.grad_checkpointing)
+            d_tr = DenoiseTrainer(d_unet, d_vae, d_train, lr=5e-6, world_size=1, text_encoder=text_encoder)
+            d_batch = synthetic_batch(frames, H, W, dev, seed=1234, with_ids=text_encoder is not None)
+            d_tr.capture(d_batch, warmup=1)
+            for _ in range(2):
+                d_tr.replay_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                d_tr.replay_step()
+            torch.cuda.synchronize()
+            default_mode_ms = round((time.perf_counter() - t1) / 10 * 1e3, 2)
+            del d_tr, d_unet, d_vae, d_train
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] default-mode (dropout) run failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     roof = None
     if rank == 0 and world == 1 and not args.no_roofline:      # per-kernel instrumentation belongs to the 1-GPU line
@@ -568,6 +655,7 @@ def main():
                     launches=rr["launches"], algorithmic_gflop_per_step=round(rr["flops"] / 1e9, 1),
                     kernel_ms_per_step=round(rr["ms"], 2), event_pair_ms_per_step=round(rr["ms_event_pairs"], 2),
                     launches_kernel_timestamped=rr["kernel_timestamped"], traffic=(pmc_traffic() or {}).get("hbm_bytes_per_launch"),
+                    traffic_source=((pmc_traffic() or {}).get("source", "") + " (separate rocprofv3 --pmc passes over this bench, not this run)") or None,
                     algorithmic_bytes_per_launch=int(rr["abytes"] / max(1, rr["launches"])),
                     algorithmic_GB_per_step=round(rr["abytes"] / 1e9, 2), traffic_detail=pmc_traffic(),
                     secondary={"kernel": "gemm_kernel<..,AT|BT> - K-major / transposed-operand launches (factor gradients of strided convs, "
@@ -599,7 +687,11 @@ def main():
                        "trainable_params": sum(p.numel() for p in trainer.opt.params),
                        "flat_gradient_elems": trainer.opt.numel, "final_loss": final_loss,
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-                       "eps_mse_rel_err": (cpu or {}).get("eps_mse_rel_err")},
+                       "eps_mse_rel_err": (cpu or {}).get("eps_mse_rel_err"),
+                       "default_mode_ms_per_step": default_mode_ms,
+                       "default_mode_note": "same clip in the reference's default train mode (LoRA dropout 0.1 + TemporalConvLayer dropout "
+                                            "0.1, masks restated in oracle/dropout.py), 10 graph replays" if default_mode_ms else None,
+                       "host_ms_per_step": host_ms},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
