@@ -499,3 +499,54 @@ def test_ddim_leading_grid_of_the_modelscope_scheduler_config():
     for t in ts:
         x = sch.step((x - acp[t].sqrt() * x0) / (1 - acp[t]).sqrt(), t, x)
     assert torch.allclose(x, acp[0].sqrt() * x0 + (1 - acp[0]).sqrt() * eps, atol=1e-9)   # final_alpha_cumprod = abar_0
+
+
+def test_stable_lora_embedding_follows_loralib():
+    """`create_lora_emb` (stable_lora/lora.py:241-248): CLIPTextEmbeddings' tables get loralib's Embedding — E[x] + (A^T[x] B^T) alpha/r,
+    A zeros / B normal, base table shared and frozen, `lora_` keys in the state dict (what reference checkpoints carry)."""
+    import torch
+    from t2v_amd.stable_lora import lora as sl
+
+    class CLIPTextEmbeddings(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.token_embedding = torch.nn.Embedding(50, 16)
+            self.position_embedding = torch.nn.Embedding(7, 16)
+
+    class TE(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embeddings = CLIPTextEmbeddings()
+
+    torch.manual_seed(0)
+    te = TE()
+    w0 = te.embeddings.token_embedding.weight
+    sl.add_lora_to(te, target_module=["CLIPTextEmbeddings"], search_class=[torch.nn.Linear, torch.nn.Embedding], r=4)()
+    emb = te.embeddings.token_embedding
+    assert isinstance(emb, sl.Embedding) and emb.weight is w0 and not emb.weight.requires_grad
+    assert emb.lora_A.shape == (4, 50) and emb.lora_B.shape == (16, 4) and emb.lora_A.requires_grad
+    assert float(emb.lora_A.abs().max()) == 0 and float(emb.lora_B.abs().max()) > 0
+    ids = torch.tensor([[1, 5, 49]])
+    assert torch.equal(emb(ids), torch.nn.functional.embedding(ids, w0))          # A = 0: inert at init
+    with torch.no_grad():
+        emb.lora_A.normal_()
+    want = torch.nn.functional.embedding(ids, w0) + (emb.lora_A.t()[ids] @ emb.lora_B.t()) * (4 / 4)
+    assert torch.allclose(emb(ids), want, atol=1e-6)
+    assert {k for k in sl.lora_state_dict(te)} == {f"embeddings.{t}.lora_{x}" for t in ("token_embedding", "position_embedding") for x in "AB"}
+
+
+def test_lr_schedules_follow_the_reference_options():
+    """train.py:606-612 -> diffusers.get_scheduler: constant / constant_with_warmup / linear / cosine multipliers."""
+    import math
+    from t2v_amd.training import lr_lambda
+    assert [lr_lambda("constant")(k) for k in (0, 10, 10 ** 6)] == [1.0, 1.0, 1.0]
+    f = lr_lambda("constant_with_warmup", 4)
+    assert [f(k) for k in range(6)] == [0.0, 0.25, 0.5, 0.75, 1.0, 1.0]
+    f = lr_lambda("linear", 2, 10)
+    assert f(0) == 0.0 and f(1) == 0.5 and f(2) == 1.0 and abs(f(6) - 0.5) < 1e-12 and f(10) == 0.0 and f(12) == 0.0
+    f = lr_lambda("cosine", 0, 8)
+    assert f(0) == 1.0 and abs(f(4) - 0.5) < 1e-12 and abs(f(8)) < 1e-12
+    assert all(f(k) >= f(k + 1) for k in range(8))
+    import pytest
+    with pytest.raises(ValueError):
+        lr_lambda("linear", 2)

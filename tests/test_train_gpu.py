@@ -455,3 +455,41 @@ def test_full_finetune_step_matches_oracle():
     print(f"full finetune (24 frames, 8x16 latent): loss oracle {float(lo):.6f} native {float(ld):.6f} rel {rel:.2e}; "
           f"whole-gradient relerr {e:.3f} (bf16 recipe floor on the 4-frame model {floor:.3f})")
     assert rel < 4e-3 and e < 2.0 * floor
+
+
+def test_gradient_accumulation_and_lr_schedule():
+    """`gradient_accumulation_steps` (train.py:481,519,848): a window of two micro-steps updates once, with the mean of the two
+    clips' gradients — the same parameters as one manual step on the accumulated buffer; and the `lr_scheduler` option scales
+    the update (warm-up step 0 has lr 0: nothing moves)."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    b = [{k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=100 + i, text_dim=64).items()} for i in range(2)]
+
+    def make(**kw):
+        ounet, ovae, dunet, dvae, _ = _build(r=4)
+        return DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=1e-3, **kw)
+
+    tr = make(gradient_accumulation_steps=2)
+    p0 = tr.opt.flat_p.clone()
+    tr.train_step(b[0])
+    torch.cuda.synchronize()
+    assert torch.equal(tr.opt.flat_p, p0) and int(tr.opt.step_count) == 0          # mid-window: no update yet
+    tr.train_step(b[1])
+    ref = make()
+    ref.opt.zero_grad()
+    ref._fwd_bwd(b[0]); ref._fwd_bwd(b[1])
+    ref.opt.step(grad_scale=0.5)
+    torch.cuda.synchronize()
+    upd, upd_ref = tr.opt.flat_p - p0, ref.opt.flat_p - p0
+    assert int(tr.opt.step_count) == 1 and float(upd_ref.norm()) > 0
+    cos = float((upd.double() * upd_ref.double()).sum() / (upd.double().norm() * upd_ref.double().norm()))
+    assert cos > 0.999 and relerr(upd, upd_ref) < 5e-2            # (fp32 atomics in the factor gradients: order only)
+    # lr schedule: constant_with_warmup(2): step 0 has multiplier 0, step 1 has 0.5
+    ws = make(lr_scheduler="constant_with_warmup", lr_warmup_steps=2)
+    q0 = ws.opt.flat_p.clone()
+    ws.train_step(b[0])
+    torch.cuda.synchronize()
+    assert relerr(ws.opt.flat_p, q0) < 1e-9                       # lr 0 (weight decay is lr-scaled too)
+    ws.train_step(b[0])
+    torch.cuda.synchronize()
+    assert float((ws.opt.flat_p - q0).norm()) > 0

@@ -122,7 +122,41 @@ class Conv3d(nn.Conv3d, LoRALayer):
         return nn.Conv3d.forward(self, x)
 
 
-_LORA_TYPES = (Linear, Conv2d, Conv3d)
+class Embedding(nn.Embedding, LoRALayer):
+    """loralib's Embedding (what `create_lora_emb`, stable_lora/lora.py:241-248, builds for CLIPTextEmbeddings' token and
+    position tables): `E[x] + (A^T[x] @ B^T) * alpha/r`, A [r, num_embeddings] zeros, B [dim, r] normal.  The text encoder runs
+    through stock torch ops, so this layer is evaluated by its own forward."""
+
+    def __init__(self, num_embeddings, embedding_dim, r=0, lora_alpha=1, merge_weights=True, **kwargs):
+        nn.Embedding.__init__(self, num_embeddings, embedding_dim, **kwargs)
+        LoRALayer.__init__(self, r, lora_alpha, 0.0, merge_weights)
+        if r > 0:
+            self.lora_A = nn.Parameter(self.weight.new_zeros((r, num_embeddings)))
+            self.lora_B = nn.Parameter(self.weight.new_zeros((embedding_dim, r)))
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+            nn.init.zeros_(self.lora_A)
+            nn.init.normal_(self.lora_B)
+
+    def delta(self):
+        return (self.lora_B @ self.lora_A).t() * self.scaling
+
+    def train(self, mode=True):
+        nn.Embedding.train(self, mode)
+        if self.merge_weights and self.r > 0 and self.merged == mode:
+            self.weight.data += self.delta() * (-1 if mode else 1)
+            self.merged = not mode
+        return self
+
+    def forward(self, x):
+        y = nn.Embedding.forward(self, x)
+        if self.r > 0 and not self.merged:
+            a = F.embedding(x, self.lora_A.t(), self.padding_idx, self.max_norm, self.norm_type, self.scale_grad_by_freq, self.sparse)
+            y = y + (a @ self.lora_B.t()) * self.scaling
+        return y
+
+
+_LORA_TYPES = (Linear, Conv2d, Conv3d, Embedding)
 
 
 def mark_only_lora_as_trainable(model, bias="none"):
@@ -186,6 +220,8 @@ def add_lora_to(model, target_module=UNET_REPLACE, search_class=(nn.Linear,), r=
         elif isinstance(child, nn.Conv3d):
             l = Conv3d(child.in_channels, child.out_channels, kernel_size=child.kernel_size[0], padding=child.padding,
                        stride=child.stride, **common)
+        elif isinstance(child, nn.Embedding):            # create_lora_emb (stable_lora/lora.py:241-248, 287-288)
+            l = Embedding(child.num_embeddings, child.embedding_dim, merge_weights=False, lora_alpha=r, r=r)
         else:
             continue
         if has_bias:

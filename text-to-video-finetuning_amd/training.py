@@ -44,6 +44,31 @@ def mse_loss(pred, target):
     return _Mse.apply(pred, target)
 
 
+def lr_lambda(name="constant", num_warmup_steps=0, num_training_steps=None):
+    """Multiplier of the base learning rate at optimiser step `k` (0-based) — the schedules `diffusers.get_scheduler` builds for
+    the reference's `lr_scheduler` / `lr_warmup_steps` / `max_train_steps` options (train.py:481,519,606-612): "constant"
+    (the default), "constant_with_warmup", "linear", "cosine"."""
+    import math
+    w, total = int(num_warmup_steps), num_training_steps
+    if name in ("linear", "cosine") and not total:
+        raise ValueError(f"lr schedule {name!r} needs num_training_steps")
+
+    def f(k):
+        if name == "constant":
+            return 1.0
+        if k < w:
+            return float(k) / float(max(1, w))
+        if name == "constant_with_warmup":
+            return 1.0
+        prog = float(k - w) / float(max(1, total - w))
+        if name == "linear":
+            return max(0.0, 1.0 - prog)
+        if name == "cosine":
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * min(1.0, prog))))
+        raise ValueError(f"unknown lr schedule {name!r}")
+    return f
+
+
 class FlatAdamW:
     """torch.optim.AdamW semantics (train.py:238-249: betas (0.9,0.999), wd 1e-2, eps 1e-8) on one flat buffer.
 
@@ -65,6 +90,8 @@ class FlatAdamW:
             world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.pg, self.world = process_group, int(world_size)
         self.last_mean_loss = None
+        self.lr_schedule = None            # optional multiplier of `lr` per optimiser step: training.lr_lambda(...)
+        self.steps_done = 0
         seen, plist = set(), []
         for p in params:
             if id(p) not in seen and p.requires_grad:
@@ -171,8 +198,10 @@ class FlatAdamW:
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         if clip:
             nv.call("t2v_sumsq", self.flat_g.data_ptr(), self.numel, self.sumsq.data_ptr(), self._sumsq_ws.data_ptr(), s)
+        lr = self.lr * (self.lr_schedule(self.steps_done) if self.lr_schedule is not None else 1.0)
+        self.steps_done += 1
         nv.call("t2v_adamw", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                self.exp_avg_sq.data_ptr(), self.numel, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 self.sumsq.data_ptr() if clip else None, float(self.max_grad_norm or 0.0), float(grad_scale),
                 self.step_count.data_ptr(), s)
         from .models.leaves import advance_dropout_step
@@ -187,7 +216,8 @@ class DenoiseTrainer:
 
     def __init__(self, unet, vae, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
                  scheduler=None, process_group=None, world_size=1, text_encoder=None, use_offset_noise=False,
-                 offset_noise_strength=0.1, rescale_schedule=False, cache_latents=False):
+                 offset_noise_strength=0.1, rescale_schedule=False, cache_latents=False, gradient_accumulation_steps=1,
+                 lr_scheduler="constant", lr_warmup_steps=0, max_train_steps=None):
         self.unet, self.vae = unet, vae
         self.text_encoder = text_encoder           # frozen CLIPTextModel (train.py:784-790); runs through stock torch ops
         self._aux_stream = None
@@ -199,6 +229,10 @@ class DenoiseTrainer:
         if rescale_schedule:
             self.scheduler.rescale_betas()         # train.py:689-690 (betas only; see schedulers.enforce_zero_terminal_snr)
         self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet, world_size=1)   # (exchange: below)
+        if lr_scheduler != "constant":      # train.py:606-612
+            self.opt.lr_schedule = lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps)
+        self.gas = max(1, int(gradient_accumulation_steps))      # train.py:481,519,848 (`accelerator.accumulate`)
+        self._micro = 0
         self.pg, self.world = process_group, world_size
         self.rank = 0
         if world_size > 1:
@@ -305,16 +339,28 @@ class DenoiseTrainer:
 
     def _exchange_and_update(self, loss):
         """DP exchange (train.py:661-667,856): ONE all-reduce(SUM) of the flat gradient buffer over RCCL/xGMI whose tail slot
-        carries this rank's loss; returns the rank-mean loss (what the reference logs after `accelerator.gather`)."""
+        carries this rank's loss; returns the rank-mean loss (what the reference logs after `accelerator.gather`).  With gradient
+        accumulation the buffer holds the SUM over the window's micro-steps: the optimiser scales by 1/window (accelerate divides
+        each micro-loss instead, train.py:848-861 — the same gradient)."""
         from .parallel import allreduce_flat_grads
         scale, mean_loss = allreduce_flat_grads(self.opt.flat_g_full, self.world, self.pg, loss=loss, tail=self.opt.numel)
-        self.opt.step(grad_scale=scale, refresh=False)     # _fwd_bwd refreshes the bf16 copies (inside the captured step)
+        self.opt.step(grad_scale=scale / self.gas, refresh=False, exchange=False)     # (_fwd_bwd refreshes the bf16 copies)
         return mean_loss
 
-    def train_step(self, batch):
-        self.opt.zero_grad()
-        loss = self._fwd_bwd(batch)
+    def _micro_step(self, run):
+        """One micro-step of an accumulation window: gradients are zeroed at the window's start, the exchange + update happen
+        at its end (in between the flat buffer just accumulates and the loss is returned as is)."""
+        if self._micro == 0:
+            self.opt.zero_grad()
+        loss = run()
+        self._micro += 1
+        if self._micro < self.gas:
+            return loss
+        self._micro = 0
         return self._exchange_and_update(loss)
+
+    def train_step(self, batch):
+        return self._micro_step(lambda: self._fwd_bwd(batch))
 
     # ---- HIP-graph replay of forward+backward (static shapes)
     def capture(self, batch, warmup=2):
@@ -343,6 +389,7 @@ class DenoiseTrainer:
             for k, v in batch.items():
                 if torch.is_tensor(v):
                     self._static[k].copy_(v)
-        self.opt.zero_grad()
-        self._graph.replay()
-        return self._exchange_and_update(self._static_loss)
+        def run():
+            self._graph.replay()
+            return self._static_loss
+        return self._micro_step(run)
