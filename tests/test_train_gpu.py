@@ -493,3 +493,28 @@ def test_gradient_accumulation_and_lr_schedule():
     ws.train_step(b[0])
     torch.cuda.synchronize()
     assert float((ws.opt.flat_p - q0).norm()) > 0
+
+
+def test_reloaded_base_weights_reach_the_merged_path():
+    """the merged weights W_eff = W + s U D are built from fp32 masters of the frozen base weights.  After a
+    `load_state_dict` that CHANGES base weights (resume, a different checkpoint) the next step — eager or graph replay — must
+    run on the new weights: the loss equals a fresh trainer's on the same state."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4)
+    fresh = copy.deepcopy(dunet)
+    batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=9, text_dim=64).items()}
+    tr = DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=0.0)
+    tr.capture(batch, warmup=1)
+    l_old = tr.replay_step(batch).item()
+    # perturb every frozen weight of both models identically
+    sd = {k: (v + 0.05 * torch.randn_like(v) if (v.dtype.is_floating_point and v.dim() > 1 and "lora" not in k) else v)
+          for k, v in dunet.state_dict().items()}
+    dunet.load_state_dict(sd); fresh.load_state_dict(sd)
+    l_new = tr.replay_step(batch).item()
+    l_eager = tr.train_step(batch).item()
+    ref = DenoiseTrainer(fresh, dvae, [p for p in fresh.parameters() if p.requires_grad], lr=0.0)
+    l_ref = ref.train_step(batch).item()
+    print(f"loss before reload {l_old:.6f}; after: replay {l_new:.6f} eager {l_eager:.6f} fresh trainer {l_ref:.6f}")
+    assert abs(l_old - l_ref) / l_ref > 1e-3                     # the perturbation matters
+    assert abs(l_new - l_ref) / l_ref < 1e-4 and abs(l_eager - l_ref) / l_ref < 1e-4

@@ -118,6 +118,25 @@ def _prep_compute(w, kind, cfg):
     return w3.flip(1).permute(2, 1, 0).reshape(kpad, taps * npad).to(BF16).contiguous()
 
 
+def resync_prepared(params):
+    """Captured graphs keep reading the cached GEMM-layout copies made by `prepared_weight`: if a frozen parameter has changed
+    since (load_state_dict / resume), re-derive its copies INTO THE SAME BUFFERS.  Returns the number of refreshed copies."""
+    n = 0
+    for w in params:
+        cache = w.__dict__.get("_t2v_prep")
+        if not cache:
+            continue
+        tag = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+        for kind, (old_tag, buf) in list(cache.items()):
+            if old_tag != tag:
+                if old_tag[2] != tag[2] or buf.device != w.device:
+                    raise RuntimeError("t2v_amd: a frozen parameter changed shape/device under a captured step; re-capture")
+                buf.copy_(_prep_compute(w, kind, None))
+                cache[kind] = (tag, buf)
+                n += 1
+    return n
+
+
 def prepared_weight(w, kind):
     """bf16 GEMM-layout copy of a parameter.  Frozen parameters cache it ON THE PARAMETER OBJECT (validated against
     storage address + version, so a re-homed / updated / re-allocated tensor can never hit a stale copy); trainable

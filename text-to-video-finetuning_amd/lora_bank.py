@@ -243,6 +243,7 @@ class MergePlan:
             entries.append((e, mod))
         self.entries = entries
         self._keep = []
+        self._base_tags = []
         jobs = (nv.LoraMergeJob * max(1, len(entries)))()
         groups_done = {}
         for k, (e, mod) in enumerate(entries):
@@ -276,6 +277,7 @@ class MergePlan:
             j.wb, j.ldwb = e.weff_bwd.data_ptr(), e.weff_bwd.stride(0)
             j.Np, j.Cp, j.taps, j.rp, j.scale = e.npad, e.cin_p, e.taps, e.rp, e.merge_scale
             self._keep.append(w32)
+            self._base_tags.append(self._tag(base.weight))
         self.njobs = len(entries)
         self.ntiles = 0
         if self.njobs:
@@ -291,6 +293,30 @@ class MergePlan:
             self.jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
             self.tile_job_dev = torch.frombuffer(bytearray(bytes(tile_job)), dtype=torch.int32).to(dev)
         self.bytes = sum(w.numel() * 4 for w in self._keep) + sum(e.weff_fwd.numel() * 4 for e, _ in entries)
+
+    @staticmethod
+    def _tag(w):
+        return (w.data_ptr(), w._version, w.device)
+
+    def sync_base(self):
+        """The fp32 masters are snapshots of the FROZEN base weights: after a `load_state_dict` / resume / `.to()` that changes
+        a base weight (new version counter or storage), re-derive that layer's master IN PLACE (the device job table keeps
+        pointing at the same buffers).  Also re-checks every wrapper's `scale` against the value baked into the job table —
+        a changed scale needs a new plan, and is refused rather than trained on silently.  Returns the number of refreshed
+        masters.  Host-side only (a few hundred attribute reads): the trainers call it once per step before the launch."""
+        from .functional import _prep_compute
+        n = 0
+        for k, (e, mod) in enumerate(self.entries):
+            w = _wrapper_parts(mod)[0].weight
+            tag = self._tag(w)
+            if tag != self._base_tags[k]:
+                self._keep[k].copy_(_prep_compute(w, "fwd32", None))
+                self._base_tags[k] = tag
+                n += 1
+            if getattr(self, "_current", None) and e.merge_scale is not None and float(mod.scale) != e.merge_scale:
+                raise RuntimeError("t2v_amd: a LoRA wrapper's scale changed after the merge plan was built "
+                                   f"({e.merge_scale} -> {float(mod.scale)}); rebuild the optimiser / trainer")
+        return n
 
     def wanted(self):
         """True if some wrapped layer can take the merged path right now: wrappers whose dropout is active (the reference's
@@ -320,6 +346,8 @@ class MergePlan:
         """Refresh every W_eff from the current fp32 factors (asynchronous on the current stream; graph-capture safe)."""
         if not self.njobs:
             return
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_base()
         if not self.wanted():
             self._mark(False)
             return

@@ -380,6 +380,9 @@ class DenoiseTrainer:
         with torch.cuda.graph(g):
             self._static_loss = self._fwd_bwd(static)
         self._graph, self._static = g, static
+        mods = [self.unet, self.vae] + ([self.text_encoder] if self.text_encoder is not None else [])
+        self._frozen = [p for m in mods if m is not None for p in m.parameters()
+                        if not p.requires_grad and "_t2v_prep" in p.__dict__]
         return self
 
     def replay_step(self, batch=None):
@@ -389,6 +392,10 @@ class DenoiseTrainer:
             for k, v in batch.items():
                 if torch.is_tensor(v):
                     self._static[k].copy_(v)
+        if getattr(self.opt, "merge", None) is not None:
+            self.opt.merge.sync_base()             # base weights re-loaded since the last step? (masters refresh in place)
+        from .functional import resync_prepared
+        resync_prepared(self._frozen)              # ... and the cached bf16 copies of the unwrapped frozen layers
         def run():
             self._graph.replay()
             return self._static_loss
