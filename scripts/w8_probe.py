@@ -145,11 +145,15 @@ for M, N, rc, K, taps, res in SHAPES:
             torch.cuda.synchronize()
             raw = ws[16384: 16384 + 4096 * 16].view(torch.int64).view(4096, 8).cpu().double()
             raw = raw[raw[:, 0] > 0]
-            t00 = raw[:, 0].min()
-            rel = raw[:, :5] - t00
-            names = ["entry", "setup done", "first stage landed", "K loop done", "stores done"]
-            print("      timeline (cycles after the first workgroup's entry; mean / max over workgroups): "
-                  + "; ".join(f"{n} {float(rel[:, i].mean()):.0f}/{float(rel[:, i].max()):.0f}" for i, n in enumerate(names)))
+            # (the cycle counters of the 8 XCDs are not aligned with each other: phase DURATIONS per workgroup only)
+            order = [0, 1, 2, 3, 5, 6, 7, 4]           # stamp slots in time order
+            stamps = raw[:, order]
+            dur = stamps[:, 1:] - stamps[:, :-1]
+            names = ["setup", "first stage in flight", "K loop", "epilogue: bias/ticket + staging of pass 0", "pass-0 outputs issued",
+                     "remaining passes", "wait for the stores"]
+            print(f"      phases of {raw.shape[0]} workgroups (cycles; mean / max): "
+                  + "; ".join(f"{n} {float(dur[:, i].mean()):.0f}/{float(dur[:, i].max()):.0f}" for i, n in enumerate(names))
+                  + f"; whole workgroup {float((raw[:, 4] - raw[:, 0]).mean()):.0f}/{float((raw[:, 4] - raw[:, 0]).max()):.0f}")
         flag = "" if err < 2e-2 else "   <-- MISMATCH"
         print(f"    cfg {cfg} ({BM[cfg]}x{BN[cfg]}) step {st:3d} split {sp} wgs {wgs:4d}: {us:7.1f} us {fl / us / 1e6:7.1f} TF/s  x{base / us:4.2f}  err {err:.1e}{flag}",
               flush=True)

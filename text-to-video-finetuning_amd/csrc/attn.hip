@@ -77,6 +77,7 @@ __device__ __forceinline__ void store_rowT(bf16_t* base, long long ss, int row, 
 }
 
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * LDT];
   const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const T2VAttn p) {
 
 // dQ (and delta = rowsum(dO * O)); one wave per 32-query block
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ __attribute__((aligned(16))) bf16_t sK[32 * LDT];
   const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
 
 // dK, dV; one wave per 32-key block
 __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * LDT];
   __shared__ __attribute__((aligned(16))) bf16_t sD[32 * LDT];
   const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
@@ -363,6 +366,7 @@ __device__ __forceinline__ bf16x8 trfrag_c(const bf16_t* lane_base) {
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ StagePair st[2];
   const bf16_t* const lds0 = (const bf16_t*)&st[0];
   constexpr int STG = sizeof(StagePair) / 2, VOFF = WG_ROWS * LDT;     // element offsets: next stage, V inside a stage
@@ -476,6 +480,7 @@ __global__ __launch_bounds__(256) void attn_fwd_wg_kernel(const T2VAttn p) {
 
 // dQ (and delta = rowsum(dO * O)); workgroup = 128 queries, K|V tiles shared
 __global__ __launch_bounds__(256) void attn_bwd_dq_wg_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ StagePair st[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -552,6 +557,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_wg_kernel(const T2VAttn p) {
 
 // dK, dV; workgroup = 128 keys, Q|dO tiles (+ their lse / delta rows) shared
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_wg_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ StagePair st[2];
   __shared__ float sL[2][WG_ROWS], sDl[2][WG_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -661,6 +667,7 @@ template <int V>
 using ic = std::integral_constant<int, V>;
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_wg2_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ StagePair st[2];
   constexpr int VOFF = WG_ROWS * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -758,6 +765,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_wg2_kernel(const T2VAttn p) {
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_wg2_kernel(const T2VAttn p) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ StagePair st[2];
   __shared__ __attribute__((aligned(16))) float sL[2][WG_ROWS], sDl[2][WG_ROWS];
   constexpr int VOFF = WG_ROWS * LDT;
@@ -917,6 +925,7 @@ __device__ __forceinline__ void load_frags(bf16x8 (&f)[4], const bf16_t* row, bo
 }
 
 __global__ __launch_bounds__(64) void attn_fwd_packed_kernel(const T2VAttn p, int S, int P) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * LDT];
   const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31, h = blockIdx.y;
   const PackedRow R = packed_row(p, S, P, l31);
@@ -963,6 +972,7 @@ __global__ __launch_bounds__(64) void attn_fwd_packed_kernel(const T2VAttn p, in
 }
 
 __global__ __launch_bounds__(64) void attn_bwd_packed_kernel(const T2VAttn p, int S, int P) {
+  warm_kernargs<(int)sizeof(T2VAttn)>();
   __shared__ __attribute__((aligned(16))) bf16_t sK[32 * LDT];
   __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * LDT];
   __shared__ __attribute__((aligned(16))) bf16_t sD[32 * LDT];

@@ -112,3 +112,17 @@ int t2v_gemm_w8_bm(int cfg);
       return T2V_ELAUNCH;                                               \
     }                                                                   \
   } while (0)
+
+// Request every cache line of the kernel-argument segment in ONE batch of scalar loads.  The compiler otherwise loads each
+// argument (field of a by-value descriptor) next to its first use; with descriptors of several cache lines the set-up of a
+// kernel then pays one memory round trip after the other — ~3000 cycles of a 20 us GEMM launch before this was added
+// (profiles/r03_w8_timeline.txt).  The later loads hit the scalar cache.
+template <int NBYTES>
+__device__ __forceinline__ void warm_kernargs() {
+  const __attribute__((address_space(4))) unsigned* ka =
+      (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned warm = 0;
+#pragma unroll
+  for (int q = 0; q < (NBYTES + 63) / 64; ++q) warm |= ka[q * 16];
+  asm volatile("" ::"s"(warm));
+}

@@ -44,7 +44,28 @@ __device__ __forceinline__ void wait_vmcnt_sel(bool first) {
   else wait_vmcnt<B>();
 }
 
-template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT>
+// Epilogue staging plan: the fp32 tile goes through LDS in as few passes as the 160 KB hold — every pass costs two or three
+// workgroup barriers and a dependent LDS write -> read -> global store chain (~2800 cycles even on an idle memory system,
+// profiles/r03_w8_timeline.txt).  A pass stages FG of the FM fragment bands of WPP = WM / WRP wave rows.
+template <int BN, int WM, int FM>
+struct EpiPlan {
+  static constexpr int LDS_MAX = 160 * 1024 - 64;
+  static constexpr int SB = BN + 4;                                         // staged row pitch (floats): 16-byte stores of 8 lanes
+                                                                            // on 8 rows land on distinct banks
+  static constexpr int BAND = 32 * SB * 4;                                  // one 32-row fragment band, fp32
+  static constexpr int WRP = (WM * BAND <= LDS_MAX) ? 1 : 2;                // wave-row groups staged separately
+  static constexpr int WPP = WM / WRP;
+  static constexpr int FG = (FM * WPP * BAND <= LDS_MAX) ? FM : ((FM % 2 == 0 && (FM / 2) * WPP * BAND <= LDS_MAX) ? FM / 2 : 1);
+  static constexpr int PROWS = FG * WPP * 32;                               // rows per staging pass
+  static constexpr int BYTES = PROWS * SB * 4;
+  static constexpr int NPASS = (FM / FG) * WRP;
+  static_assert(WM % WRP == 0 && FM % FG == 0 && BYTES <= LDS_MAX, "staging plan");
+};
+
+// CS: the instantiation with the LDS-staged epilogue (column statistics for the GroupNorm fusion need it); the other one
+// stores from registers.  Two kernels instead of a run-time branch: with both epilogues in one body the register allocator
+// spilled in each of them.
+template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS>
 __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int nstep, const int ntn, const int splits, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(WM * WN * KG == 8 && (KG == 1 || KG == 2), "eight waves: WM x WN x KG");
@@ -60,11 +81,13 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   constexpr int WROWS = 64 / CPW;                  // rows one wave covers in a pass
   static_assert(BM % RPP == 0 && BN % RPP == 0 && TM % 32 == 0 && TN % 32 == 0, "tile/wave mismatch");
   constexpr int RING_BYTES = NSTAGE * STAGE;
-  constexpr int EPI_BYTES = (WM * 32 * BN * 4 > 128 * 1024 ? WM / 2 : WM) * 32 * BN * 4;
+  using Epi = EpiPlan<BN, WM, FM>;
+  constexpr int EPI_BYTES = Epi::BYTES;
   constexpr int SMEM_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;      // + 16 bytes for the split-K ticket word
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned long long tl[5] = {0, 0, 0, 0, 0};      // timeline probe (T2V_W8_DBG=8)
+  warm_kernargs<(int)sizeof(T2VGemm) + 16>();        // (common.h)
+  unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // timeline probe (T2V_W8_DBG=8)
   if (dbg & 8) tl[0] = __builtin_readcyclecounter();
   // waves w and w+4 sit on the same SIMD: they differ in the column block, so a light and a heavy column share a matrix pipe
   const int wr = wave % WM, kg = (wave / WM) % KG, wc = wave / (WM * KG);
@@ -72,22 +95,28 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   const T2VConvGeom g = p.geom;
   // grid = output tiles x K splits (split index slowest: the splits of a tile sit ntiles apart, on the same XCD when
   // ntiles % 8 == 0); split z owns the K steps [z*nt_all/S, (z+1)*nt_all/S)
-  const int ntiles = gridDim.x / splits;
-  const int bz = blockIdx.x / ntiles, bt = blockIdx.x - bz * ntiles;
+  // (integer divisions cost ~40 instructions each on this machine: the common single-split / single-column-block launches
+  // skip them)
+  const int ntiles = splits == 1 ? (int)gridDim.x : (int)gridDim.x / splits;
+  const int bz = splits == 1 ? 0 : (int)blockIdx.x / ntiles, bt = blockIdx.x - bz * ntiles;
   int t;
   {
     int q = ntiles >> 3, r = ntiles & 7, xcd = bt & 7, idx = bt >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int nt_all = p.K / BKT;
-  const int ks0 = (int)((long long)bz * nt_all / splits), ks1 = (int)((long long)(bz + 1) * nt_all / splits);
+  const int ks0 = splits == 1 ? 0 : (int)((long long)bz * nt_all / splits);
+  const int ks1 = splits == 1 ? nt_all : (int)((long long)(bz + 1) * nt_all / splits);
   const int nt = ks1 - ks0, kbeg = ks0 * BKT;
   // raster_n & 1: an XCD's contiguous run of tiles covers a few N-tiles x ALL M-tiles (each weight column block is pulled
   // into ONE L2; the activations are streamed by every XCD) instead of a few M-tiles x all N-tiles.  What misses the L2s is
   // served at ~6 TB/s against 30+ TB/s for hits (profiles/r03_dma_bw_probe.txt), so the launcher picks the order that
   // re-streams the SMALLER operand eight times.
   int tm, tn;
-  if (p.raster_n & 1) {
+  if (ntn == 1) {
+    tm = t;
+    tn = 0;
+  } else if (p.raster_n & 1) {
     const int ntm = ntiles / ntn;
     tn = t / ntm;
     tm = t - tn * ntm;
@@ -216,6 +245,17 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     advance_window();
   };
 
+  // the ring's first stages go out BEFORE the rest of the set-up (accumulators, fragment addressing): their memory latency
+  // is the longest item in front of the first MFMA
+  constexpr int NPRO = (SCHED == 0 || SCHED == 4) ? NSTAGE - 1 : NSTAGE;
+#pragma unroll
+  for (int s = 0; s < NPRO; ++s)
+    if (s < nt) issue(kbeg + s * BKT, s);
+
+  // Accumulators hold the TRANSPOSED fragment (the weight fragment is the MFMA's first operand): lane l of fragment (i, j) has
+  // tile row i*32 + (l & 31) and, in register r, column j*32 + 8*(r >> 2) + 4*(l >> 5) + (r & 3) — four consecutive COLUMNS per
+  // register quad, which one v_permlane32_swap per register turns into eight consecutive columns per lane: the output chunk of
+  // the store (see the epilogue).
   f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -256,7 +296,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     };
     auto phase_barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
@@ -269,9 +309,6 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       // burst keeps every wave at its buffer_load for stage-bytes / 64 B per clk with the matrix pipes idle)
       constexpr int NPH = SCHED == 4 ? ((NSTAGE == 2 && KS > 1) ? KS - 1 : KS) : 1;
       constexpr int PP = (LPT + NPH - 1) / NPH;
-#pragma unroll
-      for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nt) issue(kbeg + s * BKT, s);
       int stage = 0;
       for (int it = 0; it < nt; ++it) {
         const int ahead = min(nt, it + NSTAGE - 1) - (it + 1);
@@ -304,9 +341,6 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       static_assert(KS % 2 == 0, "two fragment sets alternate per k16 step");
       constexpr int NP = KS >= 4 ? 3 : 2;                   // portions of a refill
       constexpr int PP = (LPT + NP - 1) / NP;
-#pragma unroll
-      for (int s = 0; s < NSTAGE; ++s)
-        if (s < nt) issue(kbeg + s * BKT, s);
       {
         const int ahead = min(nt, NSTAGE) - 1;
         if (ahead >= 2) wait_vmcnt<2 * LPT>();
@@ -363,9 +397,6 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       constexpr int NPH = NSTAGE == 2 ? (KS > 2 ? KS - 2 : 1) : KS;     // M phases of a stage that carry DMA pieces
       constexpr int PP = (LPT + NPH - 1) / NPH;
       const int grp = wave >> 2;
-#pragma unroll
-      for (int s = 0; s < NSTAGE; ++s)
-        if (s < nt) issue(kbeg + s * BKT, s);
       {
         const int ahead = min(nt, NSTAGE) - 1;
         if (ahead >= 2) wait_vmcnt<2 * LPT>();
@@ -420,9 +451,6 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       static_assert(KS == 2 && NSTAGE >= 3, "prefetching ping-pong: two k16 steps per stage, ring of >= 3 stages");
       constexpr int PP = (LPT + 1) / 2;
       const int grp = wave >> 2;
-#pragma unroll
-      for (int s = 0; s < NSTAGE; ++s)
-        if (s < nt) issue(kbeg + s * BKT, s);
       {
         const int ahead = min(nt, NSTAGE) - 1;
         if (ahead >= 3) wait_vmcnt<3 * LPT>();
@@ -494,10 +522,12 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   // unrolled — the first version re-loaded bias and residual inside a rolled loop and spent 8-12 us per launch on exposed
   // load latency (profiles/r03_w8_timeline.txt), more than the HBM time of the tile's stores.
   constexpr int CPR = BN / 8;
-  constexpr int WRP = (WM * 32 * BN * 4 > 128 * 1024) ? 2 : 1;      // wave-row groups staged separately (LDS budget)
-  constexpr int WPP = WM / WRP;                                     // wave rows per staging pass
-  static_assert(WM % WRP == 0, "staging split");
-  constexpr int PROWS = WPP * 32;                                   // rows per staging pass
+  constexpr int WRP = Epi::WRP, WPP = Epi::WPP, FG = Epi::FG, PROWS = Epi::PROWS, NPASS = Epi::NPASS, SB = Epi::SB;
+  // staging row rl: band rl >> 5 = fi * WPP + (wave row in the group), fragment row rl & 31; tile row of (pass ib/h, rl):
+  auto tile_row = [&](int ib, int h, int rl) {
+    const int band = rl >> 5;
+    return (h * WPP + band % WPP) * TM + (ib * FG + band / WPP) * 32 + (rl & 31);
+  };
   constexpr int RPI = NT / CPR;                                     // rows per output iteration (threads beyond RPI*CPR idle)
   constexpr int ITERS = (PROWS + RPI - 1) / RPI;
   float* sC = (float*)smem;                        // PROWS x BN fp32, one 32-row fragment band per wave row and pass
@@ -505,37 +535,10 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   const int col = n0 + cc * 8;
   const bool cact = r0 < RPI && cc * 8 < ncols;
   const bool rankcol = p.n_split > 0 && col >= p.n_split;
-  const bf16_t* R = (cact && !rankcol) ? (const bf16_t*)p.R : nullptr;
   const float alpha = p.alpha, beta = p.beta;
   const bool act_silu = p.act == T2V_ACT_SILU;
-  float cb[8];                                     // per-column additive terms: bias (+ the tile's row-bias row when it has one)
-#pragma unroll
-  for (int e = 0; e < 8; ++e) cb[e] = 0.f;
-  const bf16_t* rowbias = nullptr;                 // non-null: row-bias differs inside the tile, looked up per row
-  if (cact && !rankcol) {
-    if (p.bias) {
-      const float4 b0 = *(const float4*)((const float*)p.bias + col), b1 = *(const float4*)((const float*)p.bias + col + 4);
-      cb[0] = b0.x; cb[1] = b0.y; cb[2] = b0.z; cb[3] = b0.w; cb[4] = b1.x; cb[5] = b1.y; cb[6] = b1.z; cb[7] = b1.w;
-    }
-    if (p.rowbias) {
-      const unsigned rlo = (unsigned)m0 / (unsigned)p.rows_per_rb;
-      const unsigned rhi = (unsigned)(min((long long)M, m0 + BM) - 1) / (unsigned)p.rows_per_rb;
-      if (rlo == rhi) {
-        const bf16x8 tb = *(const bf16x8*)((const bf16_t*)p.rowbias + rlo * (unsigned)p.ldrb + col);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cb[e] += bf2f((unsigned short)tb[e]);
-      } else {
-        rowbias = (const bf16_t*)p.rowbias;
-      }
-    }
-  }
-  // ---- column statistics of the stored tile (T2VGemm.colsum, GroupNorm fusion): every thread accumulates its 8 columns over
-  // the rows it writes; the RPI threads of a column chunk are combined in fixed order through LDS after the last pass
   const int Nb = p.n_split > 0 ? p.n_split : N;
   const int cs_mode = p.colsum ? p.cs_mode : 0;
-  CsState cst;
-  cs_init(cst, p, cs_mode, cact && !rankcol, m0, col, Nb);
-  const bf16_t* CX = (cs_mode == 2 && cact && !rankcol) ? (const bf16_t*)p.cs_x : nullptr;
   // ---- split-K hand-off (splits > 1).  The splits of a tile draw a ticket when their K loop is done; the LAST one keeps its
   // partial tile in LDS / registers and becomes the reducer, the others write theirs as fp32 rows to the caller's workspace
   // (slab [tile][z]) and then count themselves done.  The reducer waits for splits-1 done marks (those workgroups finished
@@ -572,24 +575,236 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     }
   }
   const bool writer = role == 1;
-  if (writer) R = nullptr;
+
+  // ---- register epilogue (every launch without column statistics): no staging through LDS.  The transposed accumulators give
+  // a lane four consecutive columns per register quad; v_permlane32_swap between the quads q and q+1 of the two half-waves
+  // leaves lane l < 32 with columns 8q .. 8q+7 and lane l + 32 with columns 8(q+1) .. 8(q+1)+7 of tile row (l & 31): the same
+  // 8-column fp32 chunk the staged path hands to a thread, stored as 16 bytes (a wave's store covers 32 rows x 32 bytes).
+  // The staged path cost two LDS passes at the 64-79 B/clk of LDS stores plus 2-3 workgroup barriers — 9000-17000 cycles of a
+  // 20 us launch (profiles/r03_w8_timeline.txt); here the waves leave the K loop for their stores independently.
+  //   K groups (KG = 2): the groups swap HALF of their partial sums through LDS (kg 0 finishes fragment band 0 of the wave
+  //   tile, kg 1 band 1), lane-private slots, one barrier.
+  //   split-K: the slabs hold the accumulator registers as they are (lane-private float4 slots, coalesced).
+  constexpr int OWN = KG == 2 ? FM / 2 : FM;          // fragment bands a wave finishes
+  constexpr bool DIRECT_OK = KG == 1 || (FM % 2 == 0 && 8 * OWN * FN * 4096 <= SMEM_BYTES);
+  static_assert(CS || DIRECT_OK, "this configuration has no register epilogue");
+  if constexpr (!CS) {
+    {
+      auto quad = [](const f32x16& a, int q) { return make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]); };
+      if constexpr (KG == 2) {
+        constexpr int PER = OWN * FN * 4 * 64;        // float4 slots per (receiving group, wave pair)
+        float4* X = (float4*)smem;
+        const int pair = wr + WM * wc;
+        float4* xs = X + ((1 - kg) * 4 + pair) * PER + lane;
+        const float4* xr = X + (kg * 4 + pair) * PER + lane;
+        if (kg == 0) {
 #pragma unroll
-  for (int ps = 0; ps < FM * WRP; ++ps) {
-    const int i = ps / WRP, h = ps % WRP;
+          for (int io = 0; io < OWN; ++io)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) xs[((io * FN + j) * 4 + q) * 64] = quad(acc[OWN + io][j], q);
+        } else {
+#pragma unroll
+          for (int io = 0; io < OWN; ++io)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) xs[((io * FN + j) * 4 + q) * 64] = quad(acc[io][j], q);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int io = 0; io < OWN; ++io)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 x = xr[((io * FN + j) * 4 + q) * 64];
+              f32x16& d = acc[io][j];
+              if (kg == 0) {
+                d[4 * q] += x.x; d[4 * q + 1] += x.y; d[4 * q + 2] += x.z; d[4 * q + 3] += x.w;
+              } else {                                  // (kg 1 finishes band OWN + io: moved down, so that a wave's own bands
+                const f32x16& o = acc[OWN + io][j];     //  are acc[0 .. OWN) from here on)
+                d[4 * q] = o[4 * q] + x.x; d[4 * q + 1] = o[4 * q + 1] + x.y; d[4 * q + 2] = o[4 * q + 2] + x.z; d[4 * q + 3] = o[4 * q + 3] + x.w;
+              }
+            }
+      }
+      if ((dbg & 8)) tl[5] = __builtin_readcyclecounter();
+      const int ib0 = KG == 2 ? kg * OWN : 0;          // first band of the wave tile among this wave's own
+      if (role != 0) {
+        // slab slot of (wave, own band io, j, quad q, lane): coalesced 1 KiB per wave instruction
+        const long long slot0 = ((long long)wave * OWN * FN * 4) * 64 + lane;
+        float4* sl = (float4*)slab0 + slot0;
+        constexpr long long ZS = (long long)BM * BN / 4; // float4 per split slab
+        if (writer) {
+#pragma unroll
+          for (int io = 0; io < OWN; ++io)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) sl[(long long)bz * ZS + ((io * FN + j) * 4 + q) * 64] = quad(acc[io][j], q);
+        } else {
+          // ordered sum (0 + slab_0 + ... + own at position bz + ... + slab_{S-1}: independent of which split came last), a few
+          // fragments at a time so that one batch of loads is in flight per slab
+          constexpr int NFR = OWN * FN;
+          constexpr int GRP = FM * FN > 6 ? 1 : (NFR % 3 == 0 ? 3 : (NFR % 2 == 0 ? 2 : 1));
+#pragma unroll
+          for (int g0 = 0; g0 < NFR; g0 += GRP) {
+            float4 t[GRP * 4];
+#pragma unroll
+            for (int x = 0; x < GRP * 4; ++x) t[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto add_slab = [&](int z) {
+              float4 ld[GRP * 4];
+#pragma unroll
+              for (int x = 0; x < GRP * 4; ++x) ld[x] = sl[(long long)z * ZS + ((g0 * 4) + x) * 64];
+#pragma unroll
+              for (int x = 0; x < GRP * 4; ++x) {
+                t[x].x += ld[x].x; t[x].y += ld[x].y; t[x].z += ld[x].z; t[x].w += ld[x].w;
+              }
+            };
+            for (int z = 0; z < bz; ++z) add_slab(z);
+#pragma unroll
+            for (int x = 0; x < GRP * 4; ++x) {
+              const float4 own = quad(acc[(g0 + x / 4) / FN][(g0 + x / 4) % FN], x % 4);
+              t[x].x += own.x; t[x].y += own.y; t[x].z += own.z; t[x].w += own.w;
+            }
+            for (int z = bz + 1; z < splits; ++z) add_slab(z);
+#pragma unroll
+            for (int x = 0; x < GRP * 4; ++x) {
+              f32x16& d = acc[(g0 + x / 4) / FN][(g0 + x / 4) % FN];
+              const int q = x % 4;
+              d[4 * q] = t[x].x; d[4 * q + 1] = t[x].y; d[4 * q + 2] = t[x].z; d[4 * q + 3] = t[x].w;
+            }
+          }
+        }
+      }
+      if (!writer) {
+        const bf16_t* Rp = (const bf16_t*)p.R;
+        const bf16_t* rbp = (const bf16_t*)p.rowbias;
+        const float* biasp = (const float*)p.bias;
+        const int half = lane >> 5;
+        // per-chunk operands, requested one fragment ahead of their use
+        struct Pre {
+          float4 b0, b1;
+          bf16x8 rb, rv;
+        };
+        auto chunk_pos = [&](int io, int j, int qp, unsigned& row, int& ccol, bool& ok, bool& rk) {
+          row = (unsigned)m0 + wr * TM + (ib0 + io) * 32 + (lane & 31);
+          ccol = n0 + wc * TN + j * 32 + 8 * (qp + half);
+          ok = row < (unsigned)M && (ccol - n0) < ncols;
+          rk = p.n_split > 0 && ccol >= p.n_split;
+        };
+        auto prefetch = [&](int ch, Pre& pf) {
+          unsigned row;
+          int ccol;
+          bool ok, rk;
+          chunk_pos((ch >> 1) / FN, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
+          if (ok && !rk) {
+            if (biasp) {
+              pf.b0 = *(const float4*)(biasp + ccol);
+              pf.b1 = *(const float4*)(biasp + ccol + 4);
+            }
+            if (rbp) pf.rb = *(const bf16x8*)(rbp + (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + ccol);
+            if (Rp) pf.rv = *(const bf16x8*)(Rp + row * (unsigned)p.ldr + ccol);
+          }
+        };
+        Pre cur, nxt;
+        prefetch(0, cur);
+#pragma unroll
+        for (int ch = 0; ch < 2 * OWN * FN; ++ch) {      // chunk = (fragment, quad pair)
+          const int io = (ch >> 1) / FN, j = (ch >> 1) % FN, qp = 2 * (ch & 1);
+          if (ch + 1 < 2 * OWN * FN) prefetch(ch + 1, nxt);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {                // (every lane takes part in the swap: before any row / column guard)
+            const float fa = acc[io][j][4 * qp + e], fb = acc[io][j][4 * (qp + 1) + e];     // (copies: a bit_cast straight from a
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, fa),      //  vector element read element 0)
+                                                             __builtin_bit_cast(unsigned, fb), false, false);
+            const unsigned s0 = sw[0], s1 = sw[1];
+            v[e] = __builtin_bit_cast(float, s0);
+            v[4 + e] = __builtin_bit_cast(float, s1);
+          }
+          unsigned row;
+          int ccol;
+          bool ok, rk;
+          chunk_pos(io, j, qp, row, ccol, ok, rk);
+          if (ok) {
+            if (alpha != 1.f) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= alpha;
+            }
+            if (rk) {                                  // rank columns: second output block, alpha only
+              *(bf16x8*)((bf16_t*)p.D2 + row * (unsigned)p.ldd2 + (ccol - p.n_split)) = pack8bf(v);
+            } else {
+              if (biasp) {
+                v[0] += cur.b0.x; v[1] += cur.b0.y; v[2] += cur.b0.z; v[3] += cur.b0.w;
+                v[4] += cur.b1.x; v[5] += cur.b1.y; v[6] += cur.b1.z; v[7] += cur.b1.w;
+              }
+              if (rbp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bf2f((unsigned short)cur.rb[e]);
+              }
+              if (act_silu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+              }
+              if (Rp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += beta * bf2f((unsigned short)cur.rv[e]);
+              }
+              *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + ccol) = pack8bf(v);
+            }
+          }
+          if ((dbg & 8) && ch == 1) tl[6] = __builtin_readcyclecounter();
+          cur = nxt;
+        }
+      }
+    }
+  } else {
+  float cb[8];                                     // per-column additive terms: bias (+ the tile's row-bias row when it has one)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cb[e] = 0.f;
+  const bf16_t* rowbias = nullptr;                 // non-null: row-bias differs inside the tile, looked up per row
+  if (cact && !rankcol) {
+    if (p.bias) {
+      const float4 b0 = *(const float4*)((const float*)p.bias + col), b1 = *(const float4*)((const float*)p.bias + col + 4);
+      cb[0] = b0.x; cb[1] = b0.y; cb[2] = b0.z; cb[3] = b0.w; cb[4] = b1.x; cb[5] = b1.y; cb[6] = b1.z; cb[7] = b1.w;
+    }
+    if (p.rowbias) {
+      const unsigned rlo = (unsigned)m0 / (unsigned)p.rows_per_rb;
+      const unsigned rhi = (unsigned)(min((long long)M, m0 + BM) - 1) / (unsigned)p.rows_per_rb;
+      if (rlo == rhi) {
+        const bf16x8 tb = *(const bf16x8*)((const bf16_t*)p.rowbias + rlo * (unsigned)p.ldrb + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cb[e] += bf2f((unsigned short)tb[e]);
+      } else {
+        rowbias = (const bf16_t*)p.rowbias;
+      }
+    }
+  }
+  // ---- column statistics of the stored tile (T2VGemm.colsum, GroupNorm fusion): every thread accumulates its 8 columns over
+  // the rows it writes; the RPI threads of a column chunk are combined in fixed order through LDS after the last pass
+  CsState cst;
+  cs_init(cst, p, cs_mode, cact && !rankcol, m0, col, Nb);
+  const bf16_t* CX = (cs_mode == 2 && cact && !rankcol) ? (const bf16_t*)p.cs_x : nullptr;
+  const bf16_t* R = (cact && !rankcol && !writer) ? (const bf16_t*)p.R : nullptr;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int ib = ps / WRP, h = ps % WRP;
     // residual chunks of this pass: requested now, consumed after the staging barriers
     bf16x8 rv[ITERS];                                // (cs_mode 2 excludes a residual: the same registers hold the x rows)
     if (CX && role != 1) {
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const int rl = r0 + RPI * it;
-        const unsigned row = (unsigned)m0 + (h * WPP + (rl >> 5)) * TM + i * 32 + (rl & 31);
+        const unsigned row = (unsigned)m0 + tile_row(ib, h, rl);
         if (rl < PROWS && row < (unsigned)M) rv[it] = *(const bf16x8*)(CX + row * (unsigned)p.cs_ldx + col);
       }
     } else if (R) {
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const int rl = r0 + RPI * it;
-        const unsigned row = (unsigned)m0 + (h * WPP + (rl >> 5)) * TM + i * 32 + (rl & 31);
+        const unsigned row = (unsigned)m0 + tile_row(ib, h, rl);
         if (rl < PROWS && row < (unsigned)M) rv[it] = *(const bf16x8*)(R + row * (unsigned)p.ldr + col);
       }
     }
@@ -598,43 +813,64 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     const int wrl = wr % WPP;
     if (mine && (KG == 1 || kg == 1)) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+      for (int fi = 0; fi < FG; ++fi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = wrl * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int cl = wc * TN + j * 32 + (lane & 31);
-          sC[rl * BN + cl] = acc[i][j][r];
-        }
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rl = (fi * WPP + wrl) * 32 + (lane & 31);
+            const int cl = wc * TN + j * 32 + 8 * q + 4 * (lane >> 5);
+            const f32x16& a = acc[ib * FG + fi][j];
+            *(float4*)(sC + rl * SB + cl) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+          }
     }
     __syncthreads();
     if constexpr (KG == 2) {
       if (mine && kg == 0) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int fi = 0; fi < FG; ++fi)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = wrl * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int cl = wc * TN + j * 32 + (lane & 31);
-            sC[rl * BN + cl] += acc[i][j][r];
-          }
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int rl = (fi * WPP + wrl) * 32 + (lane & 31);
+              const int cl = wc * TN + j * 32 + 8 * q + 4 * (lane >> 5);
+              const f32x16& a = acc[ib * FG + fi][j];
+              float4 t = *(const float4*)(sC + rl * SB + cl);
+              t.x += a[4 * q]; t.y += a[4 * q + 1]; t.z += a[4 * q + 2]; t.w += a[4 * q + 3];
+              *(float4*)(sC + rl * SB + cl) = t;
+            }
       }
       __syncthreads();
     }
+    if ((dbg & 8) && ps == 0) tl[5] = __builtin_readcyclecounter();
     if (cact) {
+      // all staged rows of this thread are read in one batch (the row guards below are divergent branches: with the reads
+      // inside them every iteration paid its own LDS round trip)
+      constexpr int CH = NPASS > 1 ? 4 : ITERS;      // batch size (a multi-pass tile still holds live accumulators)
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
+      for (int it0 = 0; it0 < ITERS; it0 += CH) {
+      float4 sv[CH][2];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int rl = min(r0 + RPI * (it0 + q), PROWS - 1);
+        sv[q][0] = *(const float4*)(sC + rl * SB + cc * 8);
+        sv[q][1] = *(const float4*)(sC + rl * SB + cc * 8 + 4);
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int it = it0 + q;
+        if (it >= ITERS) continue;
         const int rl = r0 + RPI * it;
-        const unsigned row = (unsigned)m0 + (h * WPP + (rl >> 5)) * TM + i * 32 + (rl & 31);
+        const int trow = tile_row(ib, h, rl);
+        const unsigned row = (unsigned)m0 + trow;
         if (rl >= PROWS || row >= (unsigned)M) continue;
         float v[8];
         {
-          const float4 a = *(const float4*)(sC + rl * BN + cc * 8);
-          const float4 b = *(const float4*)(sC + rl * BN + cc * 8 + 4);
+          const float4 a = sv[q][0], b = sv[q][1];
           v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         }
         if (role != 0) {
-          // row of the tile in the slabs: (wave row band, fragment band i, row in band) -> tile row
-          const int trow = (h * WPP + (rl >> 5)) * TM + i * 32 + (rl & 31);
           float* sp = slab0 + (long long)trow * BN + cc * 8;
           if (writer) {
             float* wp = sp + (long long)bz * (BM * BN);
@@ -685,12 +921,16 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = ov;
         if (cs_mode != 0) cs_add(cst, cs_mode, ov, rv[it], p.cs_silu);
       }
+      }
     }
+    if ((dbg & 8) && ps == 0) tl[6] = __builtin_readcyclecounter();
   }
   if (cs_mode != 0 && role != 1) {
     __syncthreads();                                 // staging buffer free: [RPI][BN][2] partials of the column chunks
     cs_flush(cst, p, (float*)smem, cact && !rankcol, r0, RPI, cc, BN, tid, NT, n0, ncols, Nb, tm, BM);
   }
+  }
+  if (dbg & 8) tl[7] = __builtin_readcyclecounter();
   if (writer) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's slab rows have left
     __syncthreads();
@@ -704,14 +944,14 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the stores of this wave have left
     tl[4] = __builtin_readcyclecounter();
     unsigned long long* o = (unsigned long long*)((unsigned char*)p.workspace + 65536) + (long long)blockIdx.x * 8;   // (behind the split-K counters)
-    for (int q = 0; q < 5; ++q) o[q] = tl[q];
+    for (int q = 0; q < 8; ++q) o[q] = tl[q];
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT>
+template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS>
 int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BKT * 2;
-  constexpr int EPI = (WM * 32 * BN * 4 > 128 * 1024 ? WM / 2 : WM) * 32 * BN * 4;
+  constexpr int EPI = EpiPlan<BN, WM, BM / WM / 32>::BYTES;
   constexpr int SMEM = (RING > EPI ? RING : EPI) + 16;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   T2V_CHECK_ARG(!(p.colsum && p.cs_mode == 2) || (!p.R && p.cs_x && p.cs_sums && p.cs_gamma && p.cs_beta && p.cs_G > 0 &&
@@ -719,7 +959,7 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
                 "t2v_gemm_w8: colsum mode 2 needs x / sums / gamma / beta, no residual, and tiles inside a domain");
   T2V_CHECK_ARG(p.n_split <= 0 || p.n_split % (64 / (BKT / 8)) == 0,
                 "t2v_gemm_w8: n_split=%d must be a multiple of %d for this configuration", p.n_split, 64 / (BKT / 8));
-  auto kern = gemm_w8_kernel<BM, BN, WM, WN, KG, NSTAGE, SCHED, BKT>;
+  auto kern = gemm_w8_kernel<BM, BN, WM, WN, KG, NSTAGE, SCHED, BKT, CS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (SMEM > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -762,33 +1002,36 @@ int t2v_gemm_w8_bm(int cfg) {
   return cfg >= 0 && cfg < (int)(sizeof(bm) / sizeof(bm[0])) ? bm[cfg] : 0;
 }
 int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStream_t s) {
+  // the staged-epilogue kernels serve the launches that ask for column statistics (and T2V_W8_STAGED=1: A/B runs, tests)
+  static const bool force_staged = [] { const char* e = getenv("T2V_W8_STAGED"); return e && atoi(e) != 0; }();
+  const bool staged = p.colsum != nullptr || force_staged;
   switch (cfg) {
     //                       BM   BN  WM WN KG NS SCHED BK
-    case 0: return launch_w8<128, 384, 2, 2, 2, 2, 0, 64>(p, nstep, splits, s);      // wave 64x192, K groups, classic ring
-    case 1: return launch_w8<128, 384, 4, 2, 1, 2, 0, 64>(p, nstep, splits, s);      // wave 32x192
-    case 2: return launch_w8<256, 256, 4, 2, 1, 2, 0, 64>(p, nstep, splits, s);      // wave 64x128
-    case 3: return launch_w8<128, 192, 2, 2, 2, 3, 0, 64>(p, nstep, splits, s);      // wave 64x96, K groups, 3 stages
-    case 4: return launch_w8<128, 256, 2, 2, 2, 3, 0, 64>(p, nstep, splits, s);      // wave 64x128, K groups, 3 stages
+    case 0: return launch_w8<128, 384, 2, 2, 2, 2, 0, 64, true>(p, nstep, splits, s);      // wave 64x192, K groups, classic ring
+    case 1: return launch_w8<128, 384, 4, 2, 1, 2, 0, 64, true>(p, nstep, splits, s);      // wave 32x192
+    case 2: return launch_w8<256, 256, 4, 2, 1, 2, 0, 64, true>(p, nstep, splits, s);      // wave 64x128
+    case 3: return launch_w8<128, 192, 2, 2, 2, 3, 0, 64, true>(p, nstep, splits, s);      // wave 64x96, K groups, 3 stages
+    case 4: return launch_w8<128, 256, 2, 2, 2, 3, 0, 64, true>(p, nstep, splits, s);      // wave 64x128, K groups, 3 stages
     // ping-pong, fragments read in the M phase
-    case 5: return launch_w8<256, 256, 4, 2, 1, 2, 2, 64>(p, nstep, splits, s);
-    case 6: return launch_w8<128, 384, 2, 2, 2, 2, 2, 64>(p, nstep, splits, s);
+    case 5: return launch_w8<256, 256, 4, 2, 1, 2, 2, 64, true>(p, nstep, splits, s);
+    case 6: return launch_w8<128, 384, 2, 2, 2, 2, 2, 64, true>(p, nstep, splits, s);
     // ping-pong with prefetched fragments, 32-deep stages
-    case 7: return launch_w8<256, 256, 4, 2, 1, 4, 3, 32>(p, nstep, splits, s);      // wave 64x128, 4 x 32 KB
-    case 8: return launch_w8<256, 384, 4, 2, 1, 3, 3, 32>(p, nstep, splits, s);      // wave 64x192, 3 x 40 KB (register-bound: spills)
-    case 9: return launch_w8<128, 384, 4, 2, 1, 4, 3, 32>(p, nstep, splits, s);      // wave 32x192, 4 x 32 KB
-    case 10: return launch_w8<256, 128, 4, 2, 1, 4, 3, 32>(p, nstep, splits, s);     // wave 64x64, 4 x 24 KB
-    case 11: return launch_w8<128, 256, 2, 4, 1, 4, 3, 32>(p, nstep, splits, s);     // wave 64x64, 4 x 24 KB
+    case 7: return launch_w8<256, 256, 4, 2, 1, 4, 3, 32, true>(p, nstep, splits, s);      // wave 64x128, 4 x 32 KB
+    case 8: return launch_w8<256, 384, 4, 2, 1, 3, 3, 32, true>(p, nstep, splits, s);      // wave 64x192, 3 x 40 KB (register-bound: spills)
+    case 9: return launch_w8<128, 384, 4, 2, 1, 4, 3, 32, true>(p, nstep, splits, s);      // wave 32x192, 4 x 32 KB
+    case 10: return launch_w8<256, 128, 4, 2, 1, 4, 3, 32, true>(p, nstep, splits, s);     // wave 64x64, 4 x 24 KB
+    case 11: return launch_w8<128, 256, 2, 4, 1, 4, 3, 32, true>(p, nstep, splits, s);     // wave 64x64, 4 x 24 KB
     // classic ring with the refill pieces spread over the k16 steps
-    case 12: return launch_w8<128, 384, 4, 2, 1, 2, 4, 64>(p, nstep, splits, s);
-    case 13: return launch_w8<256, 256, 4, 2, 1, 2, 4, 64>(p, nstep, splits, s);
-    case 14: return launch_w8<128, 192, 2, 2, 2, 3, 4, 64>(p, nstep, splits, s);
-    case 15: return launch_w8<128, 384, 2, 2, 2, 2, 4, 64>(p, nstep, splits, s);
-    case 16: return launch_w8<128, 256, 2, 2, 2, 3, 4, 64>(p, nstep, splits, s);
+    case 12: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 4, 64, true>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 4, 64, false>(p, nstep, splits, s);
+    case 13: return staged ? launch_w8<256, 256, 4, 2, 1, 2, 4, 64, true>(p, nstep, splits, s) : launch_w8<256, 256, 4, 2, 1, 2, 4, 64, false>(p, nstep, splits, s);
+    case 14: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 4, 64, true>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 4, 64, false>(p, nstep, splits, s);
+    case 15: return launch_w8<128, 384, 2, 2, 2, 2, 4, 64, true>(p, nstep, splits, s);
+    case 16: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 4, 64, true>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 4, 64, false>(p, nstep, splits, s);
     // software-pipelined classic ring (fragments one k16 step ahead, barrier before the last step, refill in portions)
-    case 17: return launch_w8<128, 384, 4, 2, 1, 2, 5, 64>(p, nstep, splits, s);
-    case 18: return launch_w8<256, 256, 4, 2, 1, 2, 5, 64>(p, nstep, splits, s);
-    case 19: return launch_w8<128, 192, 2, 2, 2, 3, 5, 64>(p, nstep, splits, s);
-    case 20: return launch_w8<128, 256, 2, 2, 2, 3, 5, 64>(p, nstep, splits, s);
+    case 17: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 5, 64, true>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 5, 64, false>(p, nstep, splits, s);
+    case 18: return staged ? launch_w8<256, 256, 4, 2, 1, 2, 5, 64, true>(p, nstep, splits, s) : launch_w8<256, 256, 4, 2, 1, 2, 5, 64, false>(p, nstep, splits, s);
+    case 19: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 5, 64, true>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 5, 64, false>(p, nstep, splits, s);
+    case 20: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 5, 64, true>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 5, 64, false>(p, nstep, splits, s);
     default: t2v_set_error("t2v_gemm_w8: unknown configuration %d", cfg); return T2V_EINVAL;
   }
 }

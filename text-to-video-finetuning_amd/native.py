@@ -12,7 +12,7 @@ import sys
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2v_hip.so")
+LIB_PATH = os.environ.get("T2V_LIB_FILE") or os.path.join(_HERE, "libt2v_hip.so")      # (override: same-box A/B runs)
 TUNE_TABLE = os.environ.get("T2V_GEMM_TABLE_FILE") or os.path.join(_HERE, "gemm_tune_gfx950.txt")   # (override: A/B runs)
 
 c_void_p, c_int, c_ll, c_float, c_ull = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
