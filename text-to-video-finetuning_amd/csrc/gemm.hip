@@ -559,6 +559,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
     }
   };
 
+  // lean epilogue conditions beyond lean_ok(): bf16 output, no dropout, no split-K, whole 8-column chunks
+  const bool epi_fast = LEAN && p.out_mode == T2V_OUT_BF16 && p.ws_split <= 1 && p.drop_p == 0.f && (N & 7) == 0 && !(p.raster_n & 2);
+  EpiPre<BM, BN, WM, WN> pre;
+  if constexpr (LEAN) {
+    if (epi_fast) epi_prefetch<BM, BN, WM, WN>(p, pre, m0, n0);      // issued BEFORE the first LDS-DMA: older than every counted load
+  }
+  // ... and the ring's first stages go out before the rest of the set-up (accumulators): their latency is the longest item
+  // in front of the first MFMA
+  const int nt = (kend - kbeg + BK - 1) / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nt) issue(kbeg + s * BK, s);
+
   f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -592,16 +605,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_dma(const T2VGemm p)
     }
   };
 
-  // lean epilogue conditions beyond lean_ok(): bf16 output, no dropout, no split-K, whole 8-column chunks
-  const bool epi_fast = LEAN && p.out_mode == T2V_OUT_BF16 && p.ws_split <= 1 && p.drop_p == 0.f && (N & 7) == 0 && !(p.raster_n & 2);
-  EpiPre<BM, BN, WM, WN> pre;
-  if constexpr (LEAN) {
-    if (epi_fast) epi_prefetch<BM, BN, WM, WN>(p, pre, m0, n0);      // issued BEFORE the first LDS-DMA: older than every counted load
-  }
-  const int nt = (kend - kbeg + BK - 1) / BK;
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nt) issue(kbeg + s * BK, s);
   int stage = 0;
   for (int it = 0; it < nt; ++it) {
     const int ahead = min(nt, it + NSTAGE - 1) - (it + 1);      // tiles allowed to stay in flight

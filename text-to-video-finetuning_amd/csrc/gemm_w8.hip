@@ -591,6 +591,38 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   if constexpr (!CS) {
     {
       auto quad = [](const f32x16& a, int q) { return make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]); };
+      const int ib0 = KG == 2 ? kg * OWN : 0;          // first band of the wave tile among this wave's own
+      const bf16_t* Rp = (const bf16_t*)p.R;
+      const bf16_t* rbp = (const bf16_t*)p.rowbias;
+      const float* biasp = (const float*)p.bias;
+      const int half = lane >> 5;
+      // per-chunk operands, requested one fragment ahead of their use
+      struct Pre {
+        float4 b0, b1;
+        bf16x8 rb, rv;
+      };
+      auto chunk_pos = [&](int io, int j, int qp, unsigned& row, int& ccol, bool& ok, bool& rk) {
+        row = (unsigned)m0 + wr * TM + (ib0 + io) * 32 + (lane & 31);
+        ccol = n0 + wc * TN + j * 32 + 8 * (qp + half);
+        ok = row < (unsigned)M && (ccol - n0) < ncols;
+        rk = p.n_split > 0 && ccol >= p.n_split;
+      };
+      auto prefetch = [&](int ch, Pre& pf) {
+        unsigned row;
+        int ccol;
+        bool ok, rk;
+        chunk_pos((ch >> 1) / FN, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
+        if (ok && !rk) {
+          if (biasp) {
+            pf.b0 = *(const float4*)(biasp + ccol);
+            pf.b1 = *(const float4*)(biasp + ccol + 4);
+          }
+          if (rbp) pf.rb = *(const bf16x8*)(rbp + (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + ccol);
+          if (Rp) pf.rv = *(const bf16x8*)(Rp + row * (unsigned)p.ldr + ccol);
+        }
+      };
+      Pre cur, nxt;
+      if (KG == 2 && role == 0) prefetch(0, cur);      // (in flight under the K-group exchange)
       if constexpr (KG == 2) {
         constexpr int PER = OWN * FN * 4 * 64;        // float4 slots per (receiving group, wave pair)
         float4* X = (float4*)smem;
@@ -630,7 +662,6 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
             }
       }
       if ((dbg & 8)) tl[5] = __builtin_readcyclecounter();
-      const int ib0 = KG == 2 ? kg * OWN : 0;          // first band of the wave tile among this wave's own
       if (role != 0) {
         // slab slot of (wave, own band io, j, quad q, lane): coalesced 1 KiB per wave instruction
         const long long slot0 = ((long long)wave * OWN * FN * 4) * 64 + lane;
@@ -679,37 +710,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
       }
       if (!writer) {
-        const bf16_t* Rp = (const bf16_t*)p.R;
-        const bf16_t* rbp = (const bf16_t*)p.rowbias;
-        const float* biasp = (const float*)p.bias;
-        const int half = lane >> 5;
-        // per-chunk operands, requested one fragment ahead of their use
-        struct Pre {
-          float4 b0, b1;
-          bf16x8 rb, rv;
-        };
-        auto chunk_pos = [&](int io, int j, int qp, unsigned& row, int& ccol, bool& ok, bool& rk) {
-          row = (unsigned)m0 + wr * TM + (ib0 + io) * 32 + (lane & 31);
-          ccol = n0 + wc * TN + j * 32 + 8 * (qp + half);
-          ok = row < (unsigned)M && (ccol - n0) < ncols;
-          rk = p.n_split > 0 && ccol >= p.n_split;
-        };
-        auto prefetch = [&](int ch, Pre& pf) {
-          unsigned row;
-          int ccol;
-          bool ok, rk;
-          chunk_pos((ch >> 1) / FN, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
-          if (ok && !rk) {
-            if (biasp) {
-              pf.b0 = *(const float4*)(biasp + ccol);
-              pf.b1 = *(const float4*)(biasp + ccol + 4);
-            }
-            if (rbp) pf.rb = *(const bf16x8*)(rbp + (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + ccol);
-            if (Rp) pf.rv = *(const bf16x8*)(Rp + row * (unsigned)p.ldr + ccol);
-          }
-        };
-        Pre cur, nxt;
-        prefetch(0, cur);
+        if (KG == 1 || role != 0) prefetch(0, cur);    // (the slab reduction needs the registers)
 #pragma unroll
         for (int ch = 0; ch < 2 * OWN * FN; ++ch) {      // chunk = (fragment, quad pair)
           const int io = (ch >> 1) / FN, j = (ch >> 1) % FN, qp = 2 * (ch & 1);
