@@ -8,9 +8,9 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$root/gpurun_out/${tag}_$c
-  rocprofv3 --kernel-trace --pmc $c -d $out -o pmc -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $out -o pmc -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-default-mode > $out.log 2>&1
   db=$(find $out -name '*.db' | head -1)
-  python $root/scripts/rocpd_pmc.py $db 80 > $root/gpurun_out/${tag}_$c.txt 2>&1
+  python $root/scripts/rocpd_pmc.py $db 140 > $root/gpurun_out/${tag}_$c.txt 2>&1
   rm -rf $out
 done
 head -12 $root/gpurun_out/${tag}_FETCH_SIZE.txt | cut -c1-170

@@ -11,7 +11,8 @@ import json
 import re
 import sys
 
-FAMILIES = [("gemm_kernel_dma", "gemm_kernel_dma<...> (Linear / Conv2d / Conv3d forward + backward-data, LDS-DMA ring)"),
+GEMM_LABEL = "gemm_kernel_dma<...> + gemm_w8_kernel<...> (Linear / Conv2d / Conv3d forward + backward-data, LDS-DMA ring)"
+FAMILIES = [("gemm_kernel_dma", GEMM_LABEL), ("gemm_w8_kernel", GEMM_LABEL),
             ("gemm_kernel<", "gemm_kernel<..,AT|BT> (K-major operands)"), ("gemm_pair", "gemm_pair_kernel"),
             ("gemm_finalize", "gemm_finalize_kernel (split-K)"), ("lora_wgrad", "lora_wgrad_kernel (factor gradients)"),
             ("lora_merge", "lora_merge_kernel"), ("gn_stats_kernelILb0", "gn_stats (forward)"), ("gn_stats_kernelILb1", "gn_stats (backward)"),
@@ -45,8 +46,10 @@ def demangle_family(name):
 
 def main():
     base, dst = sys.argv[1], sys.argv[2]
-    execs = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     f, w = parse(base + "_FETCH_SIZE.txt"), parse(base + "_WRITE_SIZE.txt")
+    # executions of the step in the profiled command: the LoRA merge kernel runs exactly once per step
+    once = [v[0] for k, v in f.items() if "lora_merge_kernel" in k]
+    execs = int(sys.argv[3]) if len(sys.argv) > 3 else (once[0] if once else 4)
     fam = {}
     for name in set(f) | set(w):
         label = demangle_family(name)
@@ -68,7 +71,7 @@ def main():
                            hbm_GB_per_step=round((read_b + write_b) / execs / 1e9, 2),
                            GBps_while_running=round((read_b + write_b) / d["us"] / 1e3, 1))
     out = dict(what="rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes, scripts/pmc_step.sh) over "
-                    "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline` (config C2, shipped tile table, HIP-graph "
+                    "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-default-mode` (config C2, shipped tile table, HIP-graph "
                     f"replay): {execs} executions of the step; per-kernel-family totals",
                fetch_correction="reads = 2 x FETCH_SIZE: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16 B/lane streaming "
                                 "read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both in KB",

@@ -8,4 +8,4 @@ scol = [r[1] for r in cur.execute(f"pragma table_info({ks})").fetchall()]
 namecol = 'kernel_name' if 'kernel_name' in scol else 'display_name'
 q = f"select s.{namecol}, i.name, count(*), sum(e.value), sum(d.end-d.start) from {pe} e join {pi} i on e.pmc_id=i.id join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.{namecol}, i.name order by 4 desc"
 for n, c, k, v, t in cur.execute(q).fetchall()[:int(sys.argv[2]) if len(sys.argv) > 2 else 10]:
-    print(f"{re.sub(r'[ ]+', ' ', n)[:80]:80s} {c:12s} n={k:6d} total={v:.4e} per_launch={v/k:.1f} avg_us={t/k/1e3:.1f}")
+    print(f"{re.sub(r'[ ]+', ' ', n)[:140]:140s} {c:12s} n={k:6d} total={v:.4e} per_launch={v/k:.1f} avg_us={t/k/1e3:.1f}")

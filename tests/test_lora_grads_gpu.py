@@ -20,7 +20,7 @@ import parity_utils as pu
 
 pytestmark = pytest.mark.gpu
 FLOOR_FACTOR = 2.0
-RESULTS = os.path.join(os.path.dirname(pu.GOLDEN), "..", "gpurun_out", "parity_r02.jsonl")
+RESULTS = os.path.join(os.path.dirname(pu.GOLDEN), "..", "gpurun_out", "parity_r03.jsonl")
 
 
 def _floor(config, scale):
@@ -155,8 +155,11 @@ def _compare_with_fixture(fx, gd):
     print(f"[parity] worst sketched tensor: {worst_name} rel~{worst_big:.3f}")
     sk_rel = (num / den) ** 0.5
     # (2) norms of every tensor
-    bad_norm = [(n, float(gd[n].double().norm()), v) for n, v in fx["grad_norms"].items()
-                if v * v >= 1e-6 * gn2 and not (0.6 < float(gd[n].double().norm()) / v < 1.6)]
+    # (round-2 review: the window was 0.6 .. 1.6 — a tensor scaled by 1.5 passed; measured extremes are printed below)
+    ratios = {n: float(gd[n].double().norm()) / v for n, v in fx["grad_norms"].items() if v * v >= 1e-6 * gn2}
+    print(f"[parity] per-tensor norm ratio native/oracle over {len(ratios)} tensors: min {min(ratios.values()):.3f} "
+          f"max {max(ratios.values()):.3f}")
+    bad_norm = [(n, r * fx["grad_norms"][n], fx["grad_norms"][n]) for n, r in ratios.items() if not (0.8 < r < 1.25)]
     # (3) exact values of the sampled tensors
     go = {n: v for n, v in fx["samples"].items()}
     gs = {n: gd[n].flatten()[: v.numel()] for n, v in fx["samples"].items()}
@@ -199,7 +202,8 @@ def _assert_case(row, bad_norm):
     fl_loss, fl_grad = row["floor_loss_rel"], row["floor_grad_rel"]
     assert row["loss_rel"] < max(1e-3, FLOOR_FACTOR * fl_loss), row       # north-star bar: 1e-3 (where the recipe itself meets it)
     assert row["grad_rel_sketch"] < FLOOR_FACTOR * max(fl_grad, 0.05), row
-    assert row["worst_tensor_rel_sketch"] < 1.0, row                       # a decorrelated (mis-laid-out) tensor reads ~1.4
+    assert row["worst_tensor_rel_sketch"] < 0.5, row                       # a decorrelated (mis-laid-out) tensor reads ~1.4;
+                                                                           # measured 0.13 - 0.27 (profiles/r03_parity.jsonl)
     assert not bad_norm, bad_norm[:5]
     assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row
 
