@@ -29,8 +29,8 @@ SHAPES = [
     (512, 1280, 16, 3840, 3, 0), (512, 1280, 16, 11520, 9, 0),
     (65536, 512, 0, 4608, 9, 1), (262144, 256, 0, 2304, 9, 1), (1048576, 128, 0, 1152, 9, 0),
 ]
-BN = {0: 384, 1: 384, 2: 256, 3: 192, 4: 256, 5: 256, 6: 384, 7: 256, 8: 384, 9: 384, 10: 128, 11: 256, 12: 384, 13: 256, 14: 192, 15: 384, 16: 256, 17: 384, 18: 256, 19: 192, 20: 256}
-BM = {0: 128, 1: 128, 2: 256, 3: 128, 4: 128, 5: 256, 6: 128, 7: 256, 8: 256, 9: 128, 10: 256, 11: 128, 12: 128, 13: 256, 14: 128, 15: 128, 16: 128, 17: 128, 18: 256, 19: 128, 20: 128}
+BN = {0: 384, 1: 384, 2: 256, 3: 192, 4: 256, 5: 256, 6: 384, 7: 256, 8: 384, 9: 384, 10: 128, 11: 256, 12: 384, 13: 256, 14: 192, 15: 384, 16: 256, 17: 384, 18: 256, 19: 192, 20: 256, 21: 384, 22: 384}
+BM = {0: 128, 1: 128, 2: 256, 3: 128, 4: 128, 5: 256, 6: 128, 7: 256, 8: 256, 9: 128, 10: 256, 11: 128, 12: 128, 13: 256, 14: 128, 15: 128, 16: 128, 17: 128, 18: 256, 19: 128, 20: 128, 21: 128, 22: 128}
 ONLY = [int(x) for x in os.environ["W8_ONLY"].split(",")] if os.environ.get("W8_ONLY") else None
 
 

@@ -3,6 +3,7 @@
 
     python tests/golden/make_oracle_step.py --config c1 --scales 0,0.02,0.2
     python tests/golden/make_oracle_step.py --config c2 --scales 0.02
+    python tests/golden/make_oracle_step.py --config c3            (full finetune: gradients of all 1.41 B UNet parameters)
 
 For ModelScope-1.7B shapes with host-seeded weights/inputs (tests/parity_utils.py) the CPU fp32 oracle evaluates the
 eps-MSE of train.py:793-834 and its gradients w.r.t. all 1148 LoRA factors.  Recorded per fixture:
@@ -61,11 +62,17 @@ def main():
     import parity_utils as pu
     frames, H, W, r = pu.CONFIGS[args.config]
     from oracle.weights import synthetic_batch
+    if args.config == "c3":            # full finetune: one fixture (no LoRA factors to scale)
+        args.scales = "0"
     for scale in [float(s) for s in args.scales.split(",")]:
         t0 = time.time()
-        unet, vae, n_wrapped = pu.build_oracle(True, r, scale)
+        if args.config == "c3":
+            unet, vae = pu.build_oracle_full_finetune(True)
+            n_wrapped = 0
+        else:
+            unet, vae, n_wrapped = pu.build_oracle(True, r, scale)
         batch = synthetic_batch(frames, H, W, seed=1234)
-        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config != "c1"))
+        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config == "c2"))
         total = sum(float(g.double().pow(2).sum()) for g in grads.values()) ** 0.5
         fx = dict(config=args.config, frames=frames, height=H, width=W, rank=r, lora_up_scale=scale, seed=0, batch_seed=1234,
                   loss=loss, n_wrapped=n_wrapped, checksum=pu.weight_checksum(unet, vae), grad_norm=total,

@@ -16,6 +16,10 @@ VAE_SMALL = dict(block_out_channels=(32, 64, 64, 64))
 CONFIGS = {            # BASELINE.json configs: name -> (frames, H, W, lora rank)
     "c1": (8, 128, 128, 4),
     "c2": (16, 256, 256, 16),
+    # configs[2] (full UNet finetune, train.py:172-236: every one of the 1.41 B UNet parameters trainable, no LoRA) — the
+    # fixture is taken on the C1 clip: the weight-gradient layouts under test do not depend on the clip size, and the CPU
+    # oracle's full-size backward stays at minutes / tens of GB
+    "c3": (8, 128, 128, 0),
 }
 
 
@@ -38,6 +42,42 @@ def build_oracle(full=True, r=4, lora_up_scale=0.0, seed=0):
             m.p = 0.0
     unet.train()
     return unet, vae, len(names)
+
+
+def build_oracle_full_finetune(full=True, seed=0):
+    """CPU fp32 oracle UNet with EVERY parameter trainable (config C3) and the VAE encoder, host-seeded."""
+    from oracle.unet3d import UNet3DConditionModel
+    from oracle.vae import AutoencoderKLEncoder
+    from oracle.weights import randomize_temporal_conv4
+    torch.manual_seed(seed)
+    unet = UNet3DConditionModel(**({} if full else SMALL))
+    randomize_temporal_conv4(unet)
+    vae = AutoencoderKLEncoder(**({} if full else VAE_SMALL)).eval()
+    vae.requires_grad_(False)
+    for m in unet.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    unet.train()
+    return unet, vae
+
+
+def build_native_full_finetune(ounet, ovae, full=True):
+    import t2v_amd  # noqa: F401
+    from t2v_amd.models.unet_3d_condition import UNet3DConditionModel
+    from t2v_amd.models.vae import AutoencoderKL
+    with torch.device("meta"):
+        dunet = UNet3DConditionModel(**({} if full else SMALL))
+        dvae = AutoencoderKL(**({} if full else VAE_SMALL))
+    dunet = dunet.to_empty(device="cuda")
+    dvae = dvae.to_empty(device="cuda")
+    dunet.load_state_dict(ounet.state_dict(), strict=True)
+    dvae.load_state_dict(ovae.state_dict(), strict=True)
+    dvae.requires_grad_(False)
+    for m in dunet.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    dunet.train()
+    return dunet, dvae.eval()
 
 
 def build_native(ounet, ovae, full=True, r=4):

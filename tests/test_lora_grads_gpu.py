@@ -302,3 +302,32 @@ def test_toy_rank_beyond_the_merge_window_trains_and_matches_oracle():
     assert c["rel"] < 0.25 and c["cos"] > 0.96 and c["worst_cos"] > 0.5
     loss = trainer.train_step({k: v.cuda() for k, v in batch.items()})       # and a whole step runs
     assert torch.isfinite(loss)
+
+
+def test_c3_full_finetune_gradients_match_the_oracle_fixture():
+    """Config C3 (BASELINE.json configs[2], train.py:172-236: every UNet parameter trainable, no LoRA) at FULL model size: loss
+    and the gradient of all 1.41 B parameters — complete +-1 sketch, per-tensor norms, exact samples — against the committed
+    CPU-oracle fixture (tests/golden/make_oracle_step.py --config c3; C1 clip).  The weight gradients come from the K-major
+    GEMM family (dW = x^T dy), which no LoRA configuration exercises at full size."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    frames, H, W, _ = pu.CONFIGS["c3"]
+    ounet, ovae = pu.build_oracle_full_finetune(True)
+    fx = _load_fixture("c3", 0.0, ounet, ovae)
+    assert fx is not None, "tests/golden/oracle_step_c3_s0.pt is missing or was made for other weights"
+    dunet, dvae = pu.build_native_full_finetune(ounet, ovae)
+    del ounet, ovae
+    trainer = DenoiseTrainer(dunet, dvae, list(dunet.parameters()), lr=5e-6)
+    assert trainer.opt.merge is None and trainer.opt.numel > 1.4e9
+    batch = synthetic_batch(frames, H, W, seed=1234)
+    ld, gd = pu.native_loss_and_grads(trainer, dunet, batch)
+    sk_rel, worst_big, bad_norm, c = _compare_with_fixture(fx, gd)
+    row = dict(test="full_c3", scale=0.0, loss_oracle=fx["loss"], loss_native=ld, loss_rel=abs(ld - fx["loss"]) / abs(fx["loss"]),
+               grad_rel_sketch=sk_rel, worst_tensor_rel_sketch=worst_big, norm_outliers=len(bad_norm), sample_rel=c["rel"],
+               sample_cos=c["cos"], sample_worst_cos=c["worst_cos"], tensors=len(fx["sketches"]), fixture=True)
+    _record(**row)
+    print(row)
+    assert row["loss_rel"] < 1e-3, row
+    assert row["grad_rel_sketch"] < 0.15 and row["worst_tensor_rel_sketch"] < 0.5, row
+    assert not bad_norm, bad_norm[:5]
+    assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row

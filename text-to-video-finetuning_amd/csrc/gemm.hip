@@ -1196,7 +1196,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
     // evenly into whole fragments (or 160 / 320 = half / whole level-0 width), K splits that bring the launch to about one
     // round of workgroups
     static const int W8[][3] = {{12, 128, 384}, {17, 128, 384}, {13, 256, 256}, {18, 256, 256}, {14, 128, 192}, {19, 128, 192},
-                                {16, 128, 256}, {20, 128, 256}};
+                                {16, 128, 256}, {20, 128, 256}, {21, 128, 384}, {22, 128, 384}};
     for (const auto& w : W8) {
       const int bm = w[1], bn = w[2];
       if (p.M < bm / 2) continue;

@@ -996,10 +996,10 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
 
 // Number of W8 configurations and a pinned-configuration launch (tile table / tuning / diagnostics).  The caller (gemm.hip)
 // has already validated the descriptor and checked that the lean loader and the bf16 epilogue apply.
-extern "C" int t2v_gemm_w8_configs(void) { return 21; }
+extern "C" int t2v_gemm_w8_configs(void) { return 23; }
 // tile rows of a configuration (t2v_gemm_colsum_rows)
 int t2v_gemm_w8_bm(int cfg) {
-  static const int bm[] = {128, 128, 256, 128, 128, 256, 128, 256, 256, 128, 256, 128, 128, 256, 128, 128, 128, 128, 256, 128, 128};
+  static const int bm[] = {128, 128, 256, 128, 128, 256, 128, 256, 256, 128, 256, 128, 128, 256, 128, 128, 128, 128, 256, 128, 128, 128, 128};
   return cfg >= 0 && cfg < (int)(sizeof(bm) / sizeof(bm[0])) ? bm[cfg] : 0;
 }
 int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStream_t s) {
@@ -1033,6 +1033,10 @@ int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStre
     case 18: return staged ? launch_w8<256, 256, 4, 2, 1, 2, 5, 64, true>(p, nstep, splits, s) : launch_w8<256, 256, 4, 2, 1, 2, 5, 64, false>(p, nstep, splits, s);
     case 19: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 5, 64, true>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 5, 64, false>(p, nstep, splits, s);
     case 20: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 5, 64, true>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 5, 64, false>(p, nstep, splits, s);
+    // 128x384 with the waves 2 x 4 (wave tile 64x96 instead of 32x192: 5 instead of 7 fragment reads per 6 MFMAs — the
+    // 32x192 arrangement needs more LDS bandwidth per k16 step (56 KB of fragments + 16 KB of DMA) than its MFMAs take)
+    case 21: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 4, 64, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 4, 64, false>(p, nstep, splits, s);
+    case 22: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 5, 64, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 5, 64, false>(p, nstep, splits, s);
     default: t2v_set_error("t2v_gemm_w8: unknown configuration %d", cfg); return T2V_EINVAL;
   }
 }
