@@ -659,9 +659,13 @@ def main():
                     algorithmic_bytes_per_launch=int(rr["abytes"] / max(1, rr["launches"])),
                     algorithmic_GB_per_step=round(rr["abytes"] / 1e9, 2), traffic_detail=pmc_traffic(),
                     secondary={"kernel": "gemm_kernel<..,AT|BT> - K-major / transposed-operand launches (factor gradients of strided convs, "
-                                         "VAE attention P.V); the LoRA factor gradients proper are north_star_kernels.lora_factor_gradients",
+                                         "VAE attention P.V, and at c3 the full weight gradients); the LoRA factor gradients proper are "
+                                         "north_star_kernels.lora_factor_gradients",
                                "launches": km["launches"], "algorithmic_gflop_per_step": round(km["flops"] / 1e9, 1),
-                               "kernel_ms_per_step": round(km["ms"], 2)},
+                               "kernel_ms_per_step": round(km["ms"], 2), "bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "achieved": round(km["flops"] / max(km["ms"], 1e-9) / 1e9, 1),
+                               "frac": round(km["flops"] / max(km["ms"], 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+                               "note": "at config c3 (full finetune) this family carries every full weight gradient dW = x^T dy"},
                     graph_replay_rocprof=rocprof_family_time(rr["flops"]) if args.config == "c2" else None,
                     north_star_kernels=both["north_star"])
     cpu = None

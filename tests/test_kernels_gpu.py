@@ -104,7 +104,7 @@ def test_conv3d_temporal(B, Fr, C, HW):
 
 
 @pytest.mark.parametrize("nd,rows,C,G,silu", [(4, 63, 64, 32, True), (2, 1024, 320, 32, True), (1, 16 * 64, 640, 32, False),
-                                             (3, 10, 128, 32, False), (2, 48, 2560, 32, True)])
+                                             (3, 10, 128, 32, False), (2, 48, 2560, 32, True), (32, 1024, 320, 32, True)])
 def test_groupnorm(nd, rows, C, G, silu):
     import t2v_amd.functional as F
     g = torch.Generator().manual_seed(nd + rows + C)
@@ -125,7 +125,7 @@ def test_groupnorm(nd, rows, C, G, silu):
     assert relerr(bd.grad, btr.grad) < TOL
 
 
-@pytest.mark.parametrize("rows,C", [(100, 64), (1024, 320), (257, 1280), (64, 512)])
+@pytest.mark.parametrize("rows,C", [(100, 64), (1024, 320), (257, 1280), (64, 512), (16384, 320)])
 def test_layernorm(rows, C):
     import t2v_amd.functional as F
     g = torch.Generator().manual_seed(rows + C)

@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     const int cc = cb * tpr + tid % tpr;
     const bool active = (rl < rpp) && (cc < nchunks);
     float s0[8], s1[8];
+    float a0[8], a1[8];                               // per-channel parameter-gradient sums (full finetune only)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = a0[e] = a1[e] = 0.f;
     if (active) {
       float mean[8], rstd[8], gm[8], bt[8];
       if (BWD) {
@@ -61,11 +62,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
         }
       }
       const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-      float a0[8], a1[8];
-      if (BWD && dgamma) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
-      }
       constexpr int UN = 4;                 // independent 16-byte loads in flight per operand
       for (int r0 = rbeg + rl; r0 < rend; r0 += UN * rpp) {
         bf16x8 xq[UN], gq[UN];
@@ -113,13 +109,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
           }
         }
       }
-      if (BWD && dgamma) {                 // per-channel parameter gradients (full finetune only)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(dgamma + cc * 8 + e, a0[e]);
-          atomicAdd(dbeta + cc * 8 + e, a1[e]);
-        }
-      }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -136,6 +125,33 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
       }
     }
     __syncthreads();
+    if (BWD && dgamma) {
+      // Parameter gradients d(gamma), d(beta) (config C3): the row lanes of a chunk column are summed through LDS in lane
+      // order and the workgroup writes ONE partial row [2][C] with plain stores (`dgamma` is the partial buffer here);
+      // param_grad_reduce_kernel adds the workgroups' rows in index order.  The first version issued 16 float atomics per
+      // thread onto the same 2C addresses: 300 us per launch, 50 ms of the C3 step (profiles/r03_c3_kernel_stats.txt).
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sval[tid * 17 + e] = a0[e];
+        sval[tid * 17 + 8 + e] = a1[e];
+      }
+      __syncthreads();
+      const int ccc = cb * tpr + tid;
+      if (tid < tpr && ccc < nchunks) {
+        float* pg = dgamma + ((long long)d * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t0 = 0.f, t1 = 0.f;
+          for (int q = 0; q < rpp; ++q) {
+            t0 += sval[(q * tpr + tid) * 17 + e];
+            t1 += sval[(q * tpr + tid) * 17 + 8 + e];
+          }
+          pg[ccc * 8 + e] = t0;
+          pg[C + ccc * 8 + e] = t1;
+        }
+      }
+      __syncthreads();
+    }
   }
   // ---- last-arriving block of this domain sums the per-split partials IN FIXED ORDER (bit-reproducible whichever
   // block is last).  Hand-off in the write-through form of the agent-scope recipe (guide G16): the 4-byte partials are
@@ -401,18 +417,82 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
   }
   if (dgamma) {
+    // the four waves' per-channel sums are added through LDS in wave order, then ONE partial row [2][C] per workgroup with
+    // plain stores (`dgamma` is the partial buffer; param_grad_reduce_kernel adds the rows in index order).  The first
+    // version issued 2C float atomics per WAVE onto the same addresses: 820 us per launch, 81 ms of the C3 step.
+    extern __shared__ float lnred[];                     // [2][C]
+    for (int w = 0; w < 4; ++w) {
+      if (wv == w) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int ch = lane + 64 * i;
-      if (ch < nch) {
+        for (int i = 0; i < LN_MAXCH; ++i) {
+          const int ch = lane + 64 * i;
+          if (ch < nch) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(dgamma + ch * 8 + e, ag[i][e]);
-          atomicAdd(dbeta + ch * 8 + e, ab[i][e]);
+            for (int e = 0; e < 8; ++e) {
+              if (w == 0) {
+                lnred[ch * 8 + e] = ag[i][e];
+                lnred[C + ch * 8 + e] = ab[i][e];
+              } else {
+                lnred[ch * 8 + e] += ag[i][e];
+                lnred[C + ch * 8 + e] += ab[i][e];
+              }
+            }
+          }
         }
       }
+      __syncthreads();
+    }
+    float* pg = dgamma + (long long)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) pg[c] = lnred[c];
+  }
+}
+
+// d(gamma)[c] += sum_w partial[w][0][c], d(beta)[c] += sum_w partial[w][1][c]: 32 columns x 8 row slices per workgroup, every
+// slice summed in index order, the slices combined in slice order (fixed association: bit-reproducible)
+__global__ __launch_bounds__(256) void param_grad_reduce_kernel(const float* __restrict__ partial, int nrows, int C,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;                   // column of the [2C]-wide partial rows
+  float a = 0.f;
+  if (c < 2 * C) {
+    const int per = (nrows + 7) / 8;
+    const int r0 = sl * per, r1 = min(nrows, r0 + per);
+    for (int r = r0; r < r1; r += 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (r + u < r1) ? partial[(long long)(r + u) * 2 * C + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a += v[u];
     }
   }
+  red[sl][cl] = a;
+  __syncthreads();
+  if (sl == 0 && c < 2 * C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tot += red[q][cl];
+    if (c < C) dgamma[c] += tot;
+    else dbeta[c - C] += tot;
+  }
+}
+
+// library-owned scratch for the per-workgroup parameter-gradient partials (one buffer per device, grown outside captures)
+float* param_grad_scratch(long long floats) {
+  static float* buf[16] = {nullptr};
+  static long long cap[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (cap[dev] < floats) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    float* nb = nullptr;
+    const long long want = floats < (8ll << 20) ? (8ll << 20) : floats;     // 32 MB to begin with
+    if (hipMalloc((void**)&nb, (size_t)want * 4) != hipSuccess) return nullptr;
+    (void)st;
+    buf[dev] = nb;                                       // (the old buffer may still be read by queued kernels: it is leaked,
+    cap[dev] = want;                                     //  at most once or twice per process)
+  }
+  return buf[dev];
 }
 
 // ------------------------------------------------------------------ GroupNorm statistics from GEMM-epilogue column sums
@@ -542,10 +622,25 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
   dim3 grid(ns, ndomains);
   T2V_CHECK_ARG(ndomains <= GN_MAX_DOMAINS, "t2v_gn_bwd_stats: more than %d domains", GN_MAX_DOMAINS);
   unsigned* counters = (unsigned*)workspace;
-  T2V_LAUNCH(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch, workspace + GN_MAX_DOMAINS, dgamma,
+  float* pg = nullptr;
+  const int nwg = ns * ndomains;
+  if (dgamma) {
+    pg = param_grad_scratch((long long)nwg * 2 * C);
+    T2V_CHECK_ARG(pg, "t2v_gn_bwd_stats: cannot allocate the parameter-gradient scratch (%lld floats)", (long long)nwg * 2 * C);
+  }
+  if (dgamma)
+    T2V_LAUNCH_FIRST(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch, workspace + GN_MAX_DOMAINS, pg,
+                     dbeta, bsums, counters);
+  else
+    T2V_LAUNCH(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch, workspace + GN_MAX_DOMAINS, pg,
                      dbeta, bsums, counters);
   T2V_CHECK_LAUNCH();
+  if (dgamma) {
+    T2V_LAUNCH_LAST(param_grad_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)pg, nwg, C, dgamma, dbeta);
+    T2V_CHECK_LAUNCH();
+  }
   return T2V_OK;
 }
 
@@ -585,9 +680,22 @@ extern "C" int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, l
   T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
                 "t2v_layernorm_bwd: need C%%8==0, C<=2048 (C=%d)", C);
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_layernorm_bwd: dgamma/dbeta must both be set or NULL");
-  int grid = min((rows + 3) / 4, dgamma ? 1024 : 16384);
-  T2V_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, dgamma, dbeta, (const bf16_t*)addend, ldadd);
+  int grid = min((rows + 3) / 4, dgamma ? 2048 : 16384);
+  float* pg = nullptr;
+  if (dgamma) {
+    pg = param_grad_scratch((long long)grid * 2 * C);
+    T2V_CHECK_ARG(pg, "t2v_layernorm_bwd: cannot allocate the parameter-gradient scratch (%lld floats)", (long long)grid * 2 * C);
+  }
+  if (dgamma)
+    T2V_LAUNCH_FIRST(ln_bwd_kernel, dim3(grid), dim3(256), 2 * C * 4, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, pg, dbeta, (const bf16_t*)addend, ldadd);
+  else
+    T2V_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
+                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, pg, dbeta, (const bf16_t*)addend, ldadd);
   T2V_CHECK_LAUNCH();
+  if (dgamma) {
+    T2V_LAUNCH_LAST(param_grad_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)pg, grid, C, dgamma, dbeta);
+    T2V_CHECK_LAUNCH();
+  }
   return T2V_OK;
 }
