@@ -169,6 +169,41 @@ __device__ __forceinline__ void epilogue(const T2VGemm& p, f32x16 (&acc)[BM / (W
         sC[rl * BN + cl] = acc[i][j][r];
       }
     __syncthreads();
+    // Accumulating fp32 output with no other epilogue term (the weight-gradient launches, dW += x^T dy): consecutive lanes take
+    // consecutive columns of a row, so a wave's atomics cover two cache lines instead of sixteen, and a launch without K
+    // splits owns every element and adds with plain loads / stores.  The 8-columns-per-thread form below ran at ~40 G atomic
+    // floats/s: half of a 90 us weight-gradient launch at config C3 was its epilogue (scripts/kmajor_probe.py).
+    if (p.out_mode == T2V_OUT_F32_ATOMIC && !p.bias && !p.rowbias && !p.R && p.act == T2V_ACT_NONE && p.drop_p == 0.f &&
+        p.n_split <= 0) {
+      const bool owned = p.split_k <= 1;
+      float* Dp = (float*)p.D + zoffD;
+      if (owned && (p.ldd & 3) == 0 && (N & 3) == 0) {
+#pragma unroll 1
+        for (int c = tid; c < WM * 32 * (BN / 4); c += NT) {
+          const int rl = c / (BN / 4), c4 = c - rl * (BN / 4);
+          const long long row = m0 + (rl >> 5) * (FM * 32) + i * 32 + (rl & 31);
+          const int col = n0 + c4 * 4;
+          if (row >= M || col >= N) continue;
+          const float4 a = *(const float4*)(sC + rl * BN + c4 * 4);
+          float4* dp = (float4*)(Dp + row * p.ldd + col);
+          float4 d = *dp;
+          d.x += p.alpha * a.x; d.y += p.alpha * a.y; d.z += p.alpha * a.z; d.w += p.alpha * a.w;
+          *dp = d;
+        }
+      } else {
+#pragma unroll 1
+        for (int c = tid; c < WM * 32 * BN; c += NT) {
+          const int rl = c / BN, cl = c - rl * BN;
+          const long long row = m0 + (rl >> 5) * (FM * 32) + i * 32 + (rl & 31);
+          const int col = n0 + cl;
+          if (row >= M || col >= N) continue;
+          const float v = p.alpha * sC[rl * BN + cl];
+          if (owned) Dp[row * p.ldd + col] += v;
+          else atomicAdd(Dp + row * p.ldd + col, v);
+        }
+      }
+      continue;
+    }
 #pragma unroll 1
     for (int c = tid; c < WM * 32 * CPR; c += NT) {
       const int rl = c / CPR, cc = c - rl * CPR;
@@ -715,10 +750,13 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
     bc = nn - btap * g.C;
   }
 
-  bf16x8 ra[NCA], rb[NCB];
+  // three register sets: the global loads of K step i+3 are issued while step i computes (the operands of the weight-gradient
+  // launches stream from HBM exactly once: with ONE step of prefetch every K step paid a full memory round trip, 3.6 us per
+  // 64-deep step at config C3 — profiles/r03_c3_kernel_stats.txt)
+  bf16x8 rA[3][NCA], rB[3][NCB];
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int k0, bf16x8(&ra)[NCA], bf16x8(&rb)[NCB]) {
     if constexpr (!AT) {
       const int kidx = k0 + (tid & 7) * 8;
       const bool kok = kidx < kend;
@@ -776,7 +814,7 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
     }
   };
 
-  auto store_tiles = [&](int stage) {
+  auto store_tiles = [&](int stage, const bf16x8(&ra)[NCA], const bf16x8(&rb)[NCB]) {
     unsigned char* sA = smem + stage * STAGE;
     unsigned char* sB = sA + A_BYTES;
     if constexpr (!AT) {
@@ -862,15 +900,23 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
 
   // ---- main loop: one barrier per K step
   const int nt = (kend - kbeg + BK - 1) / BK;
-  load_tiles(kbeg);
-  store_tiles(0);
+  load_tiles(kbeg, rA[0], rB[0]);
+  if (nt > 1) load_tiles(kbeg + BK, rA[1], rB[1]);
+  if (nt > 2) load_tiles(kbeg + 2 * BK, rA[2], rB[2]);
+  store_tiles(0, rA[0], rB[0]);
   __syncthreads();
-  for (int it = 0; it < nt; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < nt) load_tiles(kbeg + (it + 1) * BK);
-    compute(cur);
-    if (it + 1 < nt) store_tiles(cur ^ 1);
-    __syncthreads();
+  for (int it = 0; it < nt; it += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {                    // K step i = it + u sits in register set u (until stored) and LDS stage i & 1
+      const int i = it + u;
+      if (i < nt) {
+        const int cur = i & 1;
+        if (i + 3 < nt) load_tiles(kbeg + (i + 3) * BK, rA[u], rB[u]);
+        compute(cur);
+        if (i + 1 < nt) store_tiles(cur ^ 1, rA[(u + 1) % 3], rB[(u + 1) % 3]);
+        __syncthreads();
+      }
+    }
   }
 
   epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, z, zoffD, zoffR);
@@ -1287,6 +1333,10 @@ int dispatch(const T2VGemm& p, hipStream_t s) {
     return (double)waves * bm * bn / eff;
   };
   if (p.N <= 32) return launch<128, 32, 4, 1, AT, BT>(p, s);   // skinny outputs (LoRA rank): HBM-bound on A
+  static const int force_tile = [] { const char* e = getenv("T2V_GEMM_FORCE_TILE"); return e ? atoi(e) : -1; }();   // probes
+  if (force_tile == 0) return launch<128, 128, 2, 2, AT, BT>(p, s);
+  if (force_tile == 1) return launch<128, 64, 2, 2, AT, BT>(p, s);
+  if (force_tile == 2) return launch<64, 64, 2, 2, AT, BT>(p, s);
   double c0 = cost(128, 128, 1.0), c1 = cost(128, 64, 0.8), c2 = cost(64, 64, 0.55);
   if (c0 <= c1 && c0 <= c2) return launch<128, 128, 2, 2, AT, BT>(p, s);
   if (c1 <= c2) return launch<128, 64, 2, 2, AT, BT>(p, s);

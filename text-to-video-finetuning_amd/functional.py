@@ -242,7 +242,9 @@ def _gemm_workspace():
 
 
 def _split_k(tiles, kdim):
-    return int(max(1, min(64, 512 // max(1, tiles), kdim // 128)))
+    """K splits of a K-major launch with `tiles` 64x64 output tiles: about 1600 workgroups (measured optimum of the weight-
+    gradient signatures at 320^2 .. 1280^2 outputs, scripts/kmajor_probe.py), at least 128 reduction rows per split."""
+    return int(max(1, min(64, 1600 // max(1, tiles), kdim // 128)))
 
 
 # --------------------------------------------------------------------------- Linear / Conv (implicit GEMM)
@@ -331,13 +333,19 @@ class _ConvLinear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             cin_p = x.shape[1]
             kw = cfg.taps() * cin_p
-            dwp = torch.zeros(npad, kw, dtype=torch.float32, device=dy.device)
+            # A Linear weight's GEMM layout IS its parameter layout: with a flat-buffer optimiser attached (`weight.grad` is
+            # a view of the fp32 gradient buffer, training.FlatAdamW) the launch accumulates straight into it and autograd gets
+            # no tensor to add — the zeros / un-permute / AccumulateGrad kernels were ~25 us per weight at config C3.
+            wg = weight.grad
+            direct = (cfg.kind == "linear" and wg is not None and wg.dtype == torch.float32 and wg.is_contiguous()
+                      and tuple(wg.shape) == (npad, kw) and not torch.is_grad_enabled())
+            dwp = wg if direct else torch.zeros(npad, kw, dtype=torch.float32, device=dy.device)
             tiles = ((npad + 63) // 64) * ((kw + 63) // 64)
             launch_gemm(M=npad, N=kw, K=M, A=g.data_ptr(), lda=_ld(g), a_trans=1, B=x.data_ptr(), ldb=_ld(x), b_trans=1,
                         b_conv=0 if cfg.kind == "linear" else 1,
                         geom=None if cfg.kind == "linear" else cfg.fwd_geom(cin_p), D=dwp.data_ptr(), ldd=kw,
                         out_mode=nv.OUT_F32_ATOMIC, alpha=alpha, split_k=_split_k(tiles, M))
-            dw = _unprep_weight_grad(dwp, weight, cfg)
+            dw = None if direct else _unprep_weight_grad(dwp, weight, cfg)
         return dx, dw, db, drb, dres, None, None, None, None, None, None
 
 
