@@ -1037,6 +1037,9 @@ int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStre
     // 32x192 arrangement needs more LDS bandwidth per k16 step (56 KB of fragments + 16 KB of DMA) than its MFMAs take)
     case 21: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 4, 64, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 4, 64, false>(p, nstep, splits, s);
     case 22: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 5, 64, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 5, 64, false>(p, nstep, splits, s);
+    // (four 32-deep stages under the classic spread-refill ring — three stages in flight instead of one — were measured as
+    //  configurations 23-26 and removed: within +-5 % of the two-stage 64-deep rings on every signature,
+    //  profiles/r03_w8_ablation.txt)
     default: t2v_set_error("t2v_gemm_w8: unknown configuration %d", cfg); return T2V_EINVAL;
   }
 }
