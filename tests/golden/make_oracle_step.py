@@ -4,6 +4,7 @@
     python tests/golden/make_oracle_step.py --config c1 --scales 0,0.02,0.2
     python tests/golden/make_oracle_step.py --config c2 --scales 0.02
     python tests/golden/make_oracle_step.py --config c3            (full finetune: gradients of all 1.41 B UNet parameters)
+    python tests/golden/make_oracle_step.py --config c1 --scales 0.02 --dropout   (default train mode, restated masks)
 
 For ModelScope-1.7B shapes with host-seeded weights/inputs (tests/parity_utils.py) the CPU fp32 oracle evaluates the
 eps-MSE of train.py:793-834 and its gradients w.r.t. all 1148 LoRA factors.  Recorded per fixture:
@@ -58,6 +59,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c1")
     ap.add_argument("--scales", default="0,0.02,0.2")
+    ap.add_argument("--dropout", action="store_true",
+                    help="the reference's DEFAULT train mode: LoRA dropout 0.1 + TemporalConvLayer dropout 0.1, with the masks of "
+                         "the native protocol restated on the CPU (oracle/dropout.py; first step of a fresh trainer)")
     args = ap.parse_args()
     import parity_utils as pu
     frames, H, W, r = pu.CONFIGS[args.config]
@@ -72,15 +76,23 @@ def main():
         else:
             unet, vae, n_wrapped = pu.build_oracle(True, r, scale)
         batch = synthetic_batch(frames, H, W, seed=1234)
-        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config == "c2"))
+        if args.dropout:
+            from oracle import dropout as odrop
+            assert args.config == "c1", "the two passes draw different masks: both are evaluated (C1 size)"
+            pu.enable_reference_dropout(unet)
+            # first _fwd_bwd of a fresh trainer: device epoch = (rank << 32) + 2, host step 0 (tests/test_lora_grads_gpu.py)
+            ctx = odrop.install_protocol(unet, pu.DROPOUT_BASE_SEED, step=0, epoch=2, batch=1, frames=frames, passes=2)
+        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config == "c2" and not args.dropout))
+        if args.dropout:
+            assert ctx["k"] == 1, "both passes must have run through the protocol"
         total = sum(float(g.double().pow(2).sum()) for g in grads.values()) ** 0.5
-        fx = dict(config=args.config, frames=frames, height=H, width=W, rank=r, lora_up_scale=scale, seed=0, batch_seed=1234,
+        fx = dict(dropout=bool(args.dropout), config=args.config, frames=frames, height=H, width=W, rank=r, lora_up_scale=scale, seed=0, batch_seed=1234,
                   loss=loss, n_wrapped=n_wrapped, checksum=pu.weight_checksum(unet, vae), grad_norm=total,
                   grad_norms={n: float(g.double().norm()) for n, g in grads.items()},
                   sketches={n: sketch(n, g) for n, g in grads.items()},
                   samples={n: grads[n].flatten()[:8192].clone() for n in sample_names(grads)},
                   torch_version=torch.__version__)
-        path = pu.fixture_path(args.config, scale)
+        path = pu.fixture_path(args.config, scale, dropout=args.dropout)
         torch.save(fx, path)
         print(f"{path}: loss {loss:.6f} |g| {total:.4e} tensors {len(grads)} samples {len(fx['samples'])} "
               f"({os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s)", flush=True)

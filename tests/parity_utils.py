@@ -103,6 +103,25 @@ def build_native(ounet, ovae, full=True, r=4):
     return dunet, dvae.eval()
 
 
+DROPOUT_BASE_SEED = 0xD0C5
+
+
+def enable_reference_dropout(net, p_lora=0.1, p_temporal=0.1):
+    """Back to the reference constructors' dropout rates (LoRA wrappers: utils/lora.py:35,89; TemporalConvLayer:
+    models/unet_3d_blocks.py:312) — build_oracle / build_native switch them off for the eval_train comparisons."""
+    for _, m in net.named_modules():
+        cls = m.__class__.__name__
+        if cls in ("LoraInjectedLinear", "LoraInjectedConv2d", "LoraInjectedConv3d"):
+            m.dropout.p = p_lora
+        elif cls == "TemporalConvLayer":
+            for seq in (m.conv2, m.conv3, m.conv4):
+                for sub in seq:
+                    if isinstance(sub, torch.nn.Dropout) or sub.__class__.__name__ == "ProtocolDropout":
+                        sub.p = p_temporal
+    net.train()
+    return net
+
+
 def weight_checksum(unet, vae):
     """Order-sensitive fp64 fingerprint of every parameter (frozen and LoRA) of both models."""
     acc, k = 0.0, 1
@@ -173,8 +192,8 @@ def compare_grads(g_ref, g_dut, share=1e-3):
                 worst_cos=worst_cos, tensors=counted, worst=per[:6])
 
 
-def fixture_path(config, scale):
-    return os.path.join(GOLDEN, f"oracle_step_{config}_s{scale:g}.pt")
+def fixture_path(config, scale, dropout=False):
+    return os.path.join(GOLDEN, f"oracle_step_{config}_s{scale:g}{'_drop' if dropout else ''}.pt")
 
 
 def sampled_names(names, every=12):

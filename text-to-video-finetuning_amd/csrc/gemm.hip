@@ -1067,6 +1067,10 @@ int colsum_bm(const T2VGemm& p, const DmaCfg& c) {
 }
 
 int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
+  static const bool trace = getenv("T2V_GEMM_TRACE") != nullptr;      // one stderr line per launch: signature -> configuration
+  if (trace)
+    fprintf(stderr, "[t2v_gemm] M=%d N=%d K=%d a_mode=%d n_split=%d res=%d conv=%dx%d C=%d colsum=%d -> tile %d stages %d split %d\n", p.M, p.N, p.K,
+            p.a_mode, p.n_split, p.R != nullptr, p.geom.KH, p.geom.KW, p.geom.C, p.colsum != nullptr, c.tile, c.stages, c.split);
   T2V_CHECK_ARG(!(p.colsum && p.cs_mode != 0) || colsum_bm(p, c) > 0,
                 "t2v_gemm: colsum requested but the kernel selected for this descriptor cannot emit it (ask t2v_gemm_colsum_rows first)");
   if (c.tile >= W8_BASE) {
