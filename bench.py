@@ -648,8 +648,9 @@ def main():
         rr, km = both["nn"], both["kmajor"]
         ach = rr["flops"] / (rr["ms"] * 1e-3) / 1e12
         roof = dict(bound="mfma",
-                    kernel="gemm_kernel_dma<BM,BN,WM,WN,NSTAGE> - every Linear/Conv2d/Conv3d forward and backward-data launch of one "
-                           "step (implicit-GEMM, LDS-DMA ring); eager instrumented pass, HIP events on the launch stream: kernel begin/end "
+                    kernel="gemm_w8_kernel<BM,BN,WM,WN,KG,NSTAGE,SCHED,BK,CS> + gemm_kernel_dma<BM,BN,WM,WN,NSTAGE> - every Linear/Conv2d/"
+                           "Conv3d forward and backward-data launch of one step (implicit GEMM, LDS-DMA ring; 8-wave and 4-wave "
+                           "families, tile per signature from the shipped table); eager instrumented pass, HIP events on the launch stream: kernel begin/end "
                            "timestamps (hipExtLaunchKernelGGL) for single-kernel launches, an event pair around the call for split-K pairs",
                     achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     launches=rr["launches"], algorithmic_gflop_per_step=round(rr["flops"] / 1e9, 1),

@@ -159,7 +159,11 @@ def _compare_with_fixture(fx, gd):
     ratios = {n: float(gd[n].double().norm()) / v for n, v in fx["grad_norms"].items() if v * v >= 1e-6 * gn2}
     print(f"[parity] per-tensor norm ratio native/oracle over {len(ratios)} tensors: min {min(ratios.values()):.3f} "
           f"max {max(ratios.values()):.3f}")
-    bad_norm = [(n, r * fx["grad_norms"][n], fx["grad_norms"][n]) for n, r in ratios.items() if not (0.8 < r < 1.25)]
+    # window: 0.8 .. 1.25 at the amplitudes a trained LoRA lives at (measured 0.97 .. 1.03); at lora_up ~ 0.2 the recipe's own
+    # bf16 run is already 6 % off in the whole gradient (floor 0.06) and single tensors scatter with the rounding path — two
+    # tile tables of the same build measured max ratios 1.20 and 1.41 there — so that amplitude keeps round 2's 0.6 .. 1.6
+    lo, hi = (0.8, 1.25) if fx.get("lora_up_scale", 0.0) < 0.1 else (0.6, 1.6)
+    bad_norm = [(n, r * fx["grad_norms"][n], fx["grad_norms"][n]) for n, r in ratios.items() if not (lo < r < hi)]
     # (3) exact values of the sampled tensors
     go = {n: v for n, v in fx["samples"].items()}
     gs = {n: gd[n].flatten()[: v.numel()] for n, v in fx["samples"].items()}
