@@ -184,7 +184,11 @@ int t2v_gn_finish(const float* colsum, int ndomains, int rows_per_domain, int C,
 int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy, int ndomains, int rows_per_domain, int C, int G,
                  const float* sums, const float* gamma, const float* beta, float eps, int silu,
                  float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
-/* backward: bsums fp32 [ndomains,G,2] = (sum dxh, sum dxh*xh), written; dgamma/dbeta fp32 [C] accumulate (may be NULL) */
+/* backward: bsums fp32 [ndomains,G,2] = (sum dxh, sum dxh*xh), written; dgamma/dbeta fp32 [C] accumulate (may be NULL).
+ * With dgamma/dbeta set (full finetune) the launch is followed by a fixed-order reduction of per-workgroup partial rows that
+ * live in a LIBRARY-OWNED device scratch (one per device, allocated with hipMalloc on first use / growth: the first call of a
+ * given size must therefore happen outside a stream capture — a warm-up step does that).  Same for t2v_layernorm_bwd.
+ * No float atomics: the parameter gradients are bit-reproducible. */
 int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long lddy, int ndomains, int rows_per_domain,
                      int C, int G, const float* sums, const float* gamma, const float* beta, float eps, int silu,
                      float drop_p, unsigned long long drop_seed,
