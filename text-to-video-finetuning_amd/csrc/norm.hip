@@ -302,59 +302,77 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row
-constexpr int LN_MAXCH = 4;  // chunks of 8 per lane -> C <= 2048
+// LN_MAXCH chunks of 8 per lane (C <= 512 * LN_MAXCH) and LN_RW rows per wave and trip are template parameters: the common
+// C = 320 rows need one chunk per lane and leave registers for eight rows in flight
 
+template <int LN_MAXCH, int LN_RW_F>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
                                                       long long ldy, int rows, int C, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* __restrict__ stats) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = C >> 3;
-  for (long long row = (long long)blockIdx.x * 4 + wv; row < rows; row += (long long)gridDim.x * 4) {
-    float v[LN_MAXCH][8];
-    float s = 0.f;
+  // LN_RW_F rows per wave and trip: the 16-byte loads of all of them are issued before the first row is reduced (one row per
+  // wave left a single load round trip in flight per wave — 2.2 TB/s at level 0)
+  for (long long row0 = ((long long)blockIdx.x * 4 + wv) * LN_RW_F; row0 < rows; row0 += (long long)gridDim.x * 4 * LN_RW_F) {
+    bf16x8 xq[LN_RW_F][LN_MAXCH];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int ch = lane + 64 * i;
-      if (ch < nch) {
-        bf16x8 xv = *(const bf16x8*)(x + row * ldx + ch * 8);
+    for (int r = 0; r < LN_RW_F; ++r)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[i][e] = bf2f((unsigned short)xv[e]);
-          s += v[i][e];
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch && row0 + r < rows) xq[r][i] = *(const bf16x8*)(x + (row0 + r) * ldx + ch * 8);
+      }
+#pragma unroll
+    for (int r = 0; r < LN_RW_F; ++r) {
+      const long long row = row0 + r;
+      if (row >= rows) break;
+      float v[LN_MAXCH][8];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
+          const bf16x8 xv = xq[r][i];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[i][e] = bf2f((unsigned short)xv[e]);
+            s += v[i][e];
+          }
         }
       }
-    }
-    const float mu = wave_sum(s) / C;
-    float q = 0.f;
+      const float mu = wave_sum(s) / C;
+      float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int ch = lane + 64 * i;
-      if (ch < nch) {
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float dlt = v[i][e] - mu;
-          q += dlt * dlt;
+          for (int e = 0; e < 8; ++e) {
+            float dlt = v[i][e] - mu;
+            q += dlt * dlt;
+          }
         }
       }
-    }
-    const float rs = rsqrtf(wave_sum(q) / C + eps);
-    if (lane == 0 && stats) {
-      stats[row * 2] = mu;
-      stats[row * 2 + 1] = rs;
-    }
+      const float rs = rsqrtf(wave_sum(q) / C + eps);
+      if (lane == 0 && stats) {
+        stats[row * 2] = mu;
+        stats[row * 2 + 1] = rs;
+      }
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int ch = lane + 64 * i;
-      if (ch < nch) {
-        bf16x8 ov;
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
+          bf16x8 ov;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf((v[i][e] - mu) * rs * gamma[ch * 8 + e] + beta[ch * 8 + e]);
-        *(bf16x8*)(y + row * ldy + ch * 8) = ov;
+          for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf((v[i][e] - mu) * rs * gamma[ch * 8 + e] + beta[ch * 8 + e]);
+          *(bf16x8*)(y + row * ldy + ch * 8) = ov;
+        }
       }
     }
   }
 }
 
+template <int LN_MAXCH, int LN_RW_B, bool PG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, long long ldx,
                                                       const bf16_t* __restrict__ dy, long long lddy,
                                                       bf16_t* __restrict__ dx, long long lddx, int rows, int C,
@@ -363,60 +381,83 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       const bf16_t* __restrict__ addend, long long ldadd) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = C >> 3;
-  float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
-  if (dgamma) {
+  float ag[PG ? LN_MAXCH : 1][8], ab[PG ? LN_MAXCH : 1][8];
+  if constexpr (PG) {
 #pragma unroll
     for (int i = 0; i < LN_MAXCH; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) ag[i][e] = ab[i][e] = 0.f;
   }
-  for (long long row = (long long)blockIdx.x * 4 + wv; row < rows; row += (long long)gridDim.x * 4) {
-    const float mu = stats[row * 2], rs = stats[row * 2 + 1];
-    float xh[LN_MAXCH][8], dh[LN_MAXCH][8];
-    float s1 = 0.f, s2 = 0.f;
+  for (long long row0 = ((long long)blockIdx.x * 4 + wv) * LN_RW_B; row0 < rows; row0 += (long long)gridDim.x * 4 * LN_RW_B) {
+    bf16x8 xq[LN_RW_B][LN_MAXCH], gq[LN_RW_B][LN_MAXCH], aq[LN_RW_B][LN_MAXCH];
+    float mus[LN_RW_B], rss[LN_RW_B];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int ch = lane + 64 * i;
-      if (ch < nch) {
-        bf16x8 xv = *(const bf16x8*)(x + row * ldx + ch * 8);
-        bf16x8 gv = *(const bf16x8*)(dy + row * lddy + ch * 8);
+    for (int r = 0; r < LN_RW_B; ++r) {
+      const long long row = row0 + r;
+      if (row < rows) {
+        mus[r] = stats[row * 2];
+        rss[r] = stats[row * 2 + 1];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float h = (bf2f((unsigned short)xv[e]) - mu) * rs;
-          float g = bf2f((unsigned short)gv[e]);
-          if (dgamma) {
-            ag[i][e] += g * h;
-            ab[i][e] += g;
+        for (int i = 0; i < LN_MAXCH; ++i) {
+          const int ch = lane + 64 * i;
+          if (ch < nch) {
+            xq[r][i] = *(const bf16x8*)(x + row * ldx + ch * 8);
+            gq[r][i] = *(const bf16x8*)(dy + row * lddy + ch * 8);
+            if (addend) aq[r][i] = *(const bf16x8*)(addend + row * ldadd + ch * 8);
           }
-          float dd = g * gamma[ch * 8 + e];
-          xh[i][e] = h;
-          dh[i][e] = dd;
-          s1 += dd;
-          s2 += dd * h;
         }
       }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int ch = lane + 64 * i;
-      if (ch < nch) {
-        bf16x8 ov;
-        if (addend) {                                     // + gradient of a pass-through (residual) use of x
-          const bf16x8 av = *(const bf16x8*)(addend + row * ldadd + ch * 8);
+    for (int r = 0; r < LN_RW_B; ++r) {
+      const long long row = row0 + r;
+      if (row >= rows) break;
+      const float mu = mus[r], rs = rss[r];
+      float xh[LN_MAXCH][8], dh[LN_MAXCH][8];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2) + bf2f((unsigned short)av[e]));
-        } else {
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
+          const bf16x8 xv = xq[r][i], gv = gq[r][i];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2));
+          for (int e = 0; e < 8; ++e) {
+            float h = (bf2f((unsigned short)xv[e]) - mu) * rs;
+            float g = bf2f((unsigned short)gv[e]);
+            if constexpr (PG) {
+              ag[i][e] += g * h;
+              ab[i][e] += g;
+            }
+            float dd = g * gamma[ch * 8 + e];
+            xh[i][e] = h;
+            dh[i][e] = dd;
+            s1 += dd;
+            s2 += dd * h;
+          }
         }
-        *(bf16x8*)(dx + row * lddx + ch * 8) = ov;
+      }
+      s1 = wave_sum(s1) / C;
+      s2 = wave_sum(s2) / C;
+#pragma unroll
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
+          bf16x8 ov;
+          if (addend) {                                     // + gradient of a pass-through (residual) use of x
+            const bf16x8 av = aq[r][i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2) + bf2f((unsigned short)av[e]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf(rs * (dh[i][e] - s1 - xh[i][e] * s2));
+          }
+          *(bf16x8*)(dx + row * lddx + ch * 8) = ov;
+        }
       }
     }
   }
-  if (dgamma) {
+  if constexpr (PG) {
     // the four waves' per-channel sums are added through LDS in wave order, then ONE partial row [2][C] per workgroup with
     // plain stores (`dgamma` is the partial buffer; param_grad_reduce_kernel adds the rows in index order).  The first
     // version issued 2C float atomics per WAVE onto the same addresses: 820 us per launch, 81 ms of the C3 step.
@@ -665,9 +706,14 @@ extern "C" int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long lon
                                  const float* beta, float eps, float* stats, t2v_stream_t stream) {
   T2V_CHECK_ARG(x && y && gamma && beta && rows > 0, "t2v_layernorm_fwd: bad args");
   T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_layernorm_fwd: need C%%8==0, C<=2048 (C=%d)", C);
-  int grid = min((rows + 3) / 4, 16384);
-  T2V_LAUNCH(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
-                     rows, C, gamma, beta, eps, stats);
+  auto go = [&](auto kern, int rw) {
+    const int grid = min((rows + 4 * rw - 1) / (4 * rw), 16384);
+    T2V_LAUNCH(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, C, gamma, beta, eps,
+               stats);
+  };
+  if (C <= 512) go(ln_fwd_kernel<1, 8>, 8);
+  else if (C <= 1024) go(ln_fwd_kernel<2, 4>, 4);
+  else go(ln_fwd_kernel<4, 2>, 2);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -680,18 +726,24 @@ extern "C" int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, l
   T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
                 "t2v_layernorm_bwd: need C%%8==0, C<=2048 (C=%d)", C);
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_layernorm_bwd: dgamma/dbeta must both be set or NULL");
-  int grid = min((rows + 3) / 4, dgamma ? 2048 : 16384);
+  const int rw = C <= 512 ? 8 : (C <= 1024 ? 4 : 2);
+  const int grid = min((rows + 4 * rw - 1) / (4 * rw), dgamma ? 2048 : 16384);
   float* pg = nullptr;
   if (dgamma) {
     pg = param_grad_scratch((long long)grid * 2 * C);
     T2V_CHECK_ARG(pg, "t2v_layernorm_bwd: cannot allocate the parameter-gradient scratch (%lld floats)", (long long)grid * 2 * C);
   }
-  if (dgamma)
-    T2V_LAUNCH_FIRST(ln_bwd_kernel, dim3(grid), dim3(256), 2 * C * 4, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, pg, dbeta, (const bf16_t*)addend, ldadd);
-  else
-    T2V_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, (bf16_t*)dx, lddx, rows, C, gamma, stats, pg, dbeta, (const bf16_t*)addend, ldadd);
+  auto go = [&](auto kern, auto kern_pg) {
+    if (dgamma)
+      T2V_LAUNCH_FIRST(kern_pg, dim3(grid), dim3(256), 2 * C * 4, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
+                       (bf16_t*)dx, lddx, rows, C, gamma, stats, pg, dbeta, (const bf16_t*)addend, ldadd);
+    else
+      T2V_LAUNCH(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx,
+                 lddx, rows, C, gamma, stats, pg, dbeta, (const bf16_t*)addend, ldadd);
+  };
+  if (C <= 512) go(ln_bwd_kernel<1, 8, false>, ln_bwd_kernel<1, 8, true>);
+  else if (C <= 1024) go(ln_bwd_kernel<2, 4, false>, ln_bwd_kernel<2, 4, true>);
+  else go(ln_bwd_kernel<4, 2, false>, ln_bwd_kernel<4, 2, true>);
   T2V_CHECK_LAUNCH();
   if (dgamma) {
     T2V_LAUNCH_LAST(param_grad_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)pg, grid, C, dgamma, dbeta);
