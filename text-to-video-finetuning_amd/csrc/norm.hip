@@ -592,11 +592,12 @@ int gn_check(const char* fn, int C, int G, long long ldx) {
   }
   return T2V_OK;
 }
-// row slabs of the apply passes: >= 8 rows per thread, up to ~2048 blocks (no cross-block reduction, so no split cap)
+// row slabs of the apply passes: >= 4 rows per thread, up to ~2048 blocks (no cross-block reduction, so no split cap)
 int gn_apply_splits(int ndomains, int rows_per_domain, int C) {
+  static const int rows_per_thread = [] { const char* e = getenv("T2V_GN_APPLY_ROWS"); return e ? max(1, atoi(e)) : 4; }();   // (4: measured optimum of {4, 8, 16} at C2)
   int rpp = 256 / min(C >> 3, 256);
   int want = max(1, 2048 / max(1, ndomains));
-  return max(1, min(want, rows_per_domain / (rpp * 8)));
+  return max(1, min(want, rows_per_domain / (rpp * rows_per_thread)));
 }
 int gn_splits(int ndomains, int rows_per_domain, int C) {
   int rpp = 256 / min(C >> 3, 256);
