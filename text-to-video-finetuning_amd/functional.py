@@ -336,7 +336,8 @@ class _ConvLinear(torch.autograd.Function):
             # A Linear weight's GEMM layout IS its parameter layout: with a flat-buffer optimiser attached (`weight.grad` is
             # a view of the fp32 gradient buffer, training.FlatAdamW) the launch accumulates straight into it and autograd gets
             # no tensor to add — the zeros / un-permute / AccumulateGrad kernels were ~25 us per weight at config C3.
-            wg = weight.grad if weight.is_leaf else None
+            # (only for parameters a FlatAdamW owns: a caller of torch.autograd.grad on a plain module must get its tensor back)
+            wg = weight.grad if (weight.is_leaf and weight.__dict__.get("_t2v_flat_grad")) else None
             direct = (cfg.kind == "linear" and wg is not None and wg.dtype == torch.float32 and wg.is_contiguous()
                       and tuple(wg.shape) == (npad, kw) and not torch.is_grad_enabled())
             dwp = wg if direct else torch.zeros(npad, kw, dtype=torch.float32, device=dy.device)

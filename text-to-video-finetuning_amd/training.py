@@ -141,6 +141,7 @@ class FlatAdamW:
             view.copy_(p.detach().float())
             p.data = view
             p.grad = gview
+            p.__dict__["_t2v_flat_grad"] = True          # opt-in marker: kernels may accumulate straight into `.grad` (functional)
             self._homes.append((p, view, gview.detach()))   # own alias of the gradient slot (p.grad's object can be re-pointed)
             offsets[id(p)] = off
             off += k
