@@ -2,7 +2,7 @@
 //
 // Same problem statement, operand loaders and epilogue semantics as gemm.hip's gemm_kernel_dma (T2VGemm: dense rows or
 // sliding-window gather on A, [N,K] weights, optional second weight/output block = the LoRA rank columns), restricted to what
-// lean_ok() admits (K % 64 == 0, C % 64 == 0, bf16 output, no dropout, no split-K workspace, offsets below 2 GiB).
+// lean_ok() admits (K % 64 == 0, C % 64 == 0, bf16 output, no dropout, offsets below 2 GiB).
 //
 // Why a second kernel: at this UNet's problem sizes (M*N <= 32768 x 336 per launch) the 4-wave kernels run 2-3 small
 // workgroups per CU and land at ~45 % of the MFMA rate in the K loop (profiles/r02_gemm_kloop_probe.txt) before tile
@@ -21,9 +21,19 @@
 //         the head of a C phase (second register set) and land under its MFMAs, a stage's LDS-DMA pieces are spread evenly
 //         over its M phases (two 1-KiB pieces per wave and phase at 256x256), and four stages give every piece two stages of
 //         landing time.
+//     4 = classic ring with the refill's LDS-DMA pieces spread over the k16 steps of the stage; 5 = 4 + fragments of the next
+//         k16 step read before the current one multiplies + the stage hand-over placed before the last k16 step (the two
+//         schedules the tuner may pick; 2 and 3 are kept for the record: they did not pay).
 //     Measured motivation (profiles/r03_w8_ablation.txt, r03_w8_phase_probe.txt, r03_dma_bw_probe.txt): with all eight waves
 //     in step, LDS-DMA issue (a stage's bytes / 64 B per clk through the CU's address path), fragment-read latency and MFMA
 //     time ADD UP per K step; the operand path itself sustains 30-38 TB/s from the L2s, so it is the overlap, not the path.
+//   * accumulators are kept TRANSPOSED (weight fragment = first MFMA operand): a lane owns one tile row and four consecutive
+//     columns per register quad, which makes the epilogue of launches without column statistics a register affair
+//     (v_permlane32_swap -> 8-column chunks -> 16-byte stores; template parameter CS = false) — see the epilogue;
+//   * in-launch split-K (ticket + fp32 slabs in the caller's workspace, reduced in split order by the last arriver);
+//   * fixed per-launch cost matters as much as the K loop at this UNet's launch sizes (a 20 us + flops/1 PFLOP/s fit over
+//     the step's 956 launches): kernel arguments are fetched in one batch, the ring prologue goes out before the rest of
+//     the set-up (profiles/r03_w8_timeline.txt).
 // LDS image, swizzle and the buffer-descriptor loader are gemm.hip's (lane-linear DMA image, XOR on source chunk + read).
 #include <stdlib.h>
 #include <type_traits>
