@@ -352,9 +352,8 @@ class MergePlan:
             self._mark(False)
             return
         self._mark(True)
-        if True:
-            from . import native as nv
-            nv.call("t2v_lora_merge", self.jobs_dev.data_ptr(), self.njobs, self.tile_job_dev.data_ptr(), self.ntiles, nv.stream())
+        from . import native as nv
+        nv.call("t2v_lora_merge", self.jobs_dev.data_ptr(), self.njobs, self.tile_job_dev.data_ptr(), self.ntiles, nv.stream())
 
 
 def is_homed(homes):
