@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 3   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
+#define T2V_ABI_VERSION 4   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -274,8 +274,18 @@ typedef struct T2VLoraWgrad {
   float* dD;       long long lddd;   /* fp32 [rp, lddd], column = tap*C + c */
   T2VConvGeom geom;
   float alpha;
+  /* ABI v4: dropout on the LoRA branch (utils/lora.py:49,119).  drop_p > 0: the dU contraction reads mask (.) dy / (1-p) with
+   * the mask of t2v_dropout_mask (index = row * N + column) regenerated on the fly — no masked copy of dy exists. */
+  float drop_p;
+  unsigned long long drop_seed;
 } T2VLoraWgrad;
 int t2v_lora_wgrad(const T2VLoraWgrad* p, t2v_stream_t stream);
+/* dt[M, rp] = (mask (.) dy / (1-p)) U^T — gradient of the down-projection output of a layer whose LoRA branch is dropped
+ * (autograd of utils/lora.py:57-62 with the dropout of :49 active).  U = bf16 [rp, ldu] rank-major (the up factor as the bank
+ * stores it), mask = t2v_dropout_mask's (index = row * N + column), regenerated in registers: dy is read once, nothing of its
+ * size is written.  rp in {8, 16, 24, 32}. */
+int t2v_lora_drop_dt(const void* dy, long long lddy, const void* U, long long ldu, void* dt, long long lddt, long long M, int N,
+                     int rp, float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
 /* The same for MANY layers in one launch (the train step queues the descriptors of a backward pass and flushes them in a few
  * batches: 568 launches of ~15 us become streaming work without per-layer ramps and tails).  `host_staging` = pinned host
  * memory and `device_table` = device memory, each of t2v_lora_wgrad_batch_bytes(nlayers) bytes, owned by the caller and left

@@ -2,30 +2,47 @@
 
 The reference draws its dropout masks from the device RNG (`nn.Dropout` in TemporalConvLayer, models/unet_3d_blocks.py:312…;
 LoRA branch, utils/lora.py:49,119), which cannot be reproduced across devices.  SURVEY 8(d) asks for a mask that is
-"identically defined on CPU and GPU": element `idx` of a tensor is kept iff
+"identically defined on CPU and GPU".  Protocol v2 (round 4; csrc/common.h `drop_key` / `drop_quad`): elements are decided
+four at a time.  With idx = row * row_width + column of the token matrix the mask is applied to (row_width % 8 == 0),
+quad q = idx >> 2, element e = idx & 3:
 
-    z = seed + (idx + 1) * 0x9E3779B97F4A7C15          (mod 2^64)
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9 ; z = (z ^ (z >> 27)) * 0x94D049BB133111EB ; z ^= z >> 31      (splitmix64)
-    u = (z >> 40) / 2^24  >=  p
+    z  = splitmix64-finaliser(seed) ; s0 = low 32 bits, s1 = high 32 bits                       (once per launch)
+    a  = fmix32((q mod 2^32) ^ s0 ^ ((q >> 32) * 0x9E3779B1))          murmur3 finaliser, 32-bit arithmetic
+    b  = (a ^ s1) * 0x9E3779B1 ; b ^= b >> 15 ; b *= 0x85EBCA77 ; b ^= b >> 13
+    field(e) = a & 0xffff, a >> 16, b & 0xffff, b >> 16      for e = 0, 1, 2, 3
+    keep  iff  field(e) >= round(p * 65536)
 
-(csrc/common.h `drop_keep`).  idx = row * row_width + column of the token matrix the mask is applied to.
+(the first protocol hashed every element with two 64-bit multiplies — the mask arithmetic bound the kernels that carry it).
 """
 import numpy as np
 import torch
 
 _M64 = (1 << 64) - 1
+_M32 = (1 << 32) - 1
 
 
 def keep_mask(seed, rows, cols, p):
-    """bool [rows, cols]: True where element (row, col) of a [rows, cols] token matrix is kept."""
-    idx = np.arange(rows * cols, dtype=np.uint64)
+    """bool [rows, cols]: True where element (row, col) of a [rows, cols] token matrix is kept (cols % 4 == 0)."""
+    if cols % 4:
+        raise ValueError("mask rows are whole quads: the column count must be a multiple of 4")
+    z = _mix64(int(seed) & _M64)
+    s0, s1 = np.uint32(z & _M32), np.uint32(z >> 32)
+    thr = np.uint32(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
+    nq = rows * cols // 4
+    q = np.arange(nq, dtype=np.uint64)
     with np.errstate(over="ignore"):
-        z = np.uint64(seed & _M64) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return torch.from_numpy((u >= np.float32(p)).reshape(rows, cols))
+        a = (q & np.uint64(_M32)).astype(np.uint32) ^ s0 ^ ((q >> np.uint64(32)).astype(np.uint32) * np.uint32(0x9E3779B1))
+        a ^= a >> np.uint32(16)
+        a *= np.uint32(0x85EBCA6B)
+        a ^= a >> np.uint32(13)
+        a *= np.uint32(0xC2B2AE35)
+        a ^= a >> np.uint32(16)
+        b = (a ^ s1) * np.uint32(0x9E3779B1)
+        b ^= b >> np.uint32(15)
+        b *= np.uint32(0x85EBCA77)
+        b ^= b >> np.uint32(13)
+    f = np.stack([a & np.uint32(0xFFFF), a >> np.uint32(16), b & np.uint32(0xFFFF), b >> np.uint32(16)], axis=1)
+    return torch.from_numpy((f >= thr).reshape(rows, cols))
 
 
 def _mix64(z):

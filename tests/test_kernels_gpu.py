@@ -304,6 +304,48 @@ def test_lora_wgrad(nimg, H, W, KH, KW, C, N, rp):
     assert eu < 1e-3 and ed < 1e-3        # fp32 accumulation of exact bf16 products: only summation order differs
 
 
+@pytest.mark.parametrize("M,N,rp,ldu_extra", [(1000, 320, 16, 0), (4096, 640, 16, 640), (77, 1280, 8, 0), (513, 2560, 32, 0),
+                                               (32, 72, 24, 0), (8192, 320, 16, 0)])
+def test_lora_drop_dt_and_masked_wgrad(M, N, rp, ldu_extra):
+    """Backward of a dropped LoRA branch without a masked copy of dy (utils/lora.py:49,57-62 autograd): t2v_lora_drop_dt gives
+    dt = (mask . dy / (1-p)) U from ONE masked pass over dy, and T2VLoraWgrad.drop_p makes the dU contraction regenerate the
+    same mask (oracle/dropout.keep_mask, index = row * N + column).  fp32 references on the bf16 operands."""
+    import ctypes as C_
+    import t2v_amd.native as nv
+    from oracle.dropout import keep_mask
+    p, seed = 0.1, 0xABCDEF123 + M
+    g = torch.Generator().manual_seed(M + N + rp)
+    dy = _bf(torch.randn(M, N, generator=g)); U = _bf(torch.randn(rp, N + ldu_extra, generator=g) * 0.3)
+    t = _bf(torch.randn(M, rp, generator=g)); x = _bf(torch.randn(M, 64, generator=g)); dt_in = _bf(torch.randn(M, rp, generator=g))
+    m = keep_mask(seed, M, N, p).float() / (1.0 - p)
+    gm = dy.float() * m
+    ref_dt = gm @ U[:, :N].float().T
+    dyd, Ud, dt = dy.cuda(), U.cuda(), torch.full((M, rp), 7.0, dtype=torch.bfloat16, device="cuda")
+    nv.call("t2v_lora_drop_dt", dyd.data_ptr(), N, Ud.data_ptr(), N + ldu_extra, dt.data_ptr(), rp, M, N, rp, p, seed, nv.stream())
+    torch.cuda.synchronize()
+    e = relerr(dt, ref_dt)
+    print("lora_drop_dt relerr", e)
+    assert e < 6e-3                       # exact bf16 products, fp32 sums, one bf16 rounding of the result
+    # masked dU (and an unmasked dD in the same descriptor)
+    a = 0.5
+    dU0 = torch.randn(rp, N, generator=g); dD0 = torch.randn(rp, 64, generator=g)
+    refU = dU0 + a * (t.float().T @ gm)
+    refD = dD0 + a * (dt_in.float().T @ x.float())
+    td, dtd, xd, dU, dD = t.cuda(), dt_in.cuda(), x.cuda(), dU0.cuda(), dD0.cuda()
+    w = nv.LoraWgrad()
+    w.rows, w.rp, w.conv = M, rp, 0
+    w.t, w.ldt, w.dy, w.lddy, w.N = td.data_ptr(), rp, dyd.data_ptr(), N, N
+    w.dU, w.lddu = dU.data_ptr(), N
+    w.dt, w.lddt, w.x, w.ldx, w.C = dtd.data_ptr(), rp, xd.data_ptr(), 64, 64
+    w.dD, w.lddd = dD.data_ptr(), 64
+    w.alpha, w.drop_p, w.drop_seed = a, p, seed
+    nv.call("t2v_lora_wgrad", C_.byref(w), nv.stream())
+    torch.cuda.synchronize()
+    eu, ed = relerr(dU, refU), relerr(dD, refD)
+    print("masked wgrad relerr", eu, ed)
+    assert eu < 1e-3 and ed < 1e-3
+
+
 def test_lora_wgrad_batch_equals_per_layer_launches():
     """t2v_lora_wgrad_batch: the descriptors of several layers (linear, 3x3, (3,1,1); one or two rank passes; different row
     counts) in ONE launch give what the per-layer launches give (fp32 atomics: summation order only)."""

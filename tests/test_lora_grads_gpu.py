@@ -277,8 +277,13 @@ def test_toy_default_train_mode_with_dropout_matches_oracle(scale):
     for m in ounet.modules():
         if m.__class__.__name__ == "ProtocolDropout":
             m.p = 0.0
-    l_off, _ = pu.oracle_loss_and_grads(ounet, ovae, batch)
-    assert abs(l_off - l_ref) / abs(l_ref) > 10 * max(rel, 1e-4)
+    l_off, g_off = pu.oracle_loss_and_grads(ounet, ovae, batch)
+    off = pu.compare_grads(g_ref, g_off)
+    print(f"oracle with its masks switched off: loss moves {abs(l_off - l_ref) / abs(l_ref):.2e}, gradients rel {off['rel']:.3f}")
+    # (the size of the loss shift depends on the drawn masks: 2e-3 .. 7e-3 over the two protocol versions; the gradients of the
+    #  dropped branches move by ~sqrt(p / (1 - p)) whatever the draw)
+    assert abs(l_off - l_ref) / abs(l_ref) > 3 * max(rel, 1e-4)
+    assert off["rel"] > cmp["rel"]
 
 
 def test_toy_rank_beyond_the_merge_window_trains_and_matches_oracle():

@@ -13,8 +13,12 @@ SOURCES = ["gemm.hip", "gemm_w8.hip", "norm.hip", "attn.hip", "elementwise.hip",
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + ["common.h"]:
+    # every source AND every header under csrc/ (colsum.h is included by both GEMM files: an edit there must not ship a
+    # stale library behind a matching stamp)
+    headers = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
+    for f in SOURCES + headers:
         with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode())
             h.update(fh.read())
     with open(os.path.join(INCLUDE, "t2v_abi.h"), "rb") as fh:
         h.update(fh.read())
@@ -29,14 +33,30 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    # per-object stamps (source + every header): an edit to one .hip recompiles that object only
+    hh = hashlib.sha256()
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith(".h")):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            hh.update(f.encode())
+            hh.update(fh.read())
+    with open(os.path.join(INCLUDE, "t2v_abi.h"), "rb") as fh:
+        hh.update(fh.read())
+    stamps = {}
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        h = hh.copy()
+        with open(os.path.join(CSRC, src), "rb") as fh:
+            h.update(fh.read())
+        stamps[obj] = h.hexdigest()
+        ostamp = obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == stamps[obj]:
+            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
                "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
     failed = False
     for src, pr in procs:
         out, _ = pr.communicate()
@@ -45,6 +65,10 @@ def build(force=False, verbose=True):
             sys.stderr.write(f"--- {src} failed ---\n{out}\n")
         elif verbose and out.strip():
             print(out)
+        else:
+            obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+            with open(obj + ".sha256", "w") as f:
+                f.write(stamps[obj])
     if failed:
         raise RuntimeError("hipcc failed")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -49,13 +49,80 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, 
   return epoch ? seed ^ mix64(*epoch + 0x9E3779B97F4A7C15ull) : seed;
 }
 
-// counter-based dropout keep decision: splitmix64 of (seed, element index)
-__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, float p) {
-  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p;
+// Counter-based dropout keep decision (protocol v2, round 4; restated in oracle/dropout.py).
+// Elements are decided FOUR AT A TIME: quad q = idx >> 2 of the token matrix (idx = row * width + column; width % 8 == 0, so
+// a quad never straddles rows) gets two 32-bit hashes built from 32-bit multiplies only, element e = idx & 3 takes one
+// 16-bit field of them and is kept iff field >= round(p * 65536).  The first version hashed every element with splitmix64
+// (two 64-bit multiplies = ~100 VALU cycles per element on a part whose 32-bit integer multiply is quarter rate): the
+// streaming kernels that carry a mask were ALU-bound by it and a GEMM epilogue could not afford it at all.  One quad costs
+// 4 multiplies + ~12 simple operations.
+//   key   : z = mix64(seed) (seed = eff_seed(...), uniform per launch); s0 = low word, s1 = high word
+//   a     = fmix32((uint32)q ^ s0 ^ (uint32)(q >> 32) * 0x9E3779B1)            (murmur3 finaliser: a bijection of q)
+//   b     = ((a ^ s1) * 0x9E3779B1; b ^= b >> 15; b *= 0x85EBCA77; b ^= b >> 13)
+//   field : e = 0: a & 0xffff, 1: a >> 16, 2: b & 0xffff, 3: b >> 16
+struct DropKey {
+  unsigned s0, s1, thr;
+};
+__device__ __forceinline__ DropKey drop_key(unsigned long long seed, float p) {
+  const unsigned long long z = mix64(seed);
+  DropKey k;
+  k.s0 = (unsigned)z;
+  k.s1 = (unsigned)(z >> 32);
+  k.thr = (unsigned)(p * 65536.f + 0.5f);
+  return k;
+}
+struct DropQuad {
+  unsigned a, b;
+};
+__device__ __forceinline__ DropQuad drop_quad(const DropKey& k, unsigned long long q) {
+  unsigned a = (unsigned)q ^ k.s0 ^ ((unsigned)(q >> 32) * 0x9E3779B1u);
+  a ^= a >> 16;
+  a *= 0x85EBCA6Bu;
+  a ^= a >> 13;
+  a *= 0xC2B2AE35u;
+  a ^= a >> 16;
+  unsigned b = (a ^ k.s1) * 0x9E3779B1u;
+  b ^= b >> 15;
+  b *= 0x85EBCA77u;
+  b ^= b >> 13;
+  return DropQuad{a, b};
+}
+// keep decision of element e (0..3) of a quad
+__device__ __forceinline__ bool quad_keep(const DropKey& k, const DropQuad& h, int e) {
+  const unsigned w = (e & 2) ? h.b : h.a;
+  const unsigned f = (e & 1) ? (w >> 16) : (w & 0xffffu);
+  return f >= k.thr;
+}
+// v[0..3] = keep ? v * ks : 0 for the four elements of quad q
+__device__ __forceinline__ void drop_apply4(const DropKey& k, unsigned long long q, float ks, float& v0, float& v1, float& v2, float& v3) {
+  const DropQuad h = drop_quad(k, q);
+  v0 = (h.a & 0xffffu) >= k.thr ? v0 * ks : 0.f;
+  v1 = (h.a >> 16) >= k.thr ? v1 * ks : 0.f;
+  v2 = (h.b & 0xffffu) >= k.thr ? v2 * ks : 0.f;
+  v3 = (h.b >> 16) >= k.thr ? v3 * ks : 0.f;
+}
+// eight consecutive elements starting at idx (idx % 4 == 0): two quads
+__device__ __forceinline__ void drop_apply8(const DropKey& k, unsigned long long idx, float ks, float (&v)[8]) {
+  drop_apply4(k, idx >> 2, ks, v[0], v[1], v[2], v[3]);
+  drop_apply4(k, (idx >> 2) + 1, ks, v[4], v[5], v[6], v[7]);
+}
+// keep bits of eight consecutive elements starting at idx (idx % 4 == 0): bit e set = element idx + e is kept
+__device__ __forceinline__ unsigned drop_bits8(const DropKey& k, unsigned long long idx) {
+  const DropQuad h0 = drop_quad(k, idx >> 2), h1 = drop_quad(k, (idx >> 2) + 1);
+  unsigned m = 0;
+  m |= (h0.a & 0xffffu) >= k.thr ? 1u : 0u;
+  m |= (h0.a >> 16) >= k.thr ? 2u : 0u;
+  m |= (h0.b & 0xffffu) >= k.thr ? 4u : 0u;
+  m |= (h0.b >> 16) >= k.thr ? 8u : 0u;
+  m |= (h1.a & 0xffffu) >= k.thr ? 16u : 0u;
+  m |= (h1.a >> 16) >= k.thr ? 32u : 0u;
+  m |= (h1.b & 0xffffu) >= k.thr ? 64u : 0u;
+  m |= (h1.b >> 16) >= k.thr ? 128u : 0u;
+  return m;
+}
+// single element (slow path: tails, per-element kernels)
+__device__ __forceinline__ bool drop_keep(const DropKey& k, unsigned long long idx) {
+  return quad_keep(k, drop_quad(k, idx >> 2), (int)(idx & 3));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -198,13 +198,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restr
 __global__ __launch_bounds__(256) void dropout_mask_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
                                                             long long ldy, long long rows, int cols, float p,
                                                             unsigned long long seed_in, const unsigned long long* __restrict__ epoch) {
-  const unsigned long long seed = eff_seed(seed_in, epoch);
+  const DropKey dkey = drop_key(eff_seed(seed_in, epoch), p);
   const float ks = 1.f / (1.f - p);
-  const long long n = rows * cols;
+  const int cpr = cols >> 3;                       // 8-column chunks per row (cols % 8 == 0: checked by the entry point)
+  const long long n = rows * cpr;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    long long r = i / cols;
-    int c = (int)(i - r * cols);
-    y[r * ldy + c] = drop_keep(seed, (unsigned long long)i, p) ? f2bf(bf2f(x[r * ldx + c]) * ks) : (bf16_t)0;
+    const long long r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    const bf16x8 v = *(const bf16x8*)(x + r * ldx + c);
+    const unsigned kb = drop_bits8(dkey, (unsigned long long)r * cols + c);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((kb >> e) & 1u) ? (short)f2bf(bf2f((unsigned short)v[e]) * ks) : (short)0;
+    *(bf16x8*)(y + r * ldy + c) = o;
   }
 }
 
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict_
                                                               long long M, int N, float scale, int rows_per_block,
                                                               float drop_p, unsigned long long drop_seed_in,
                                                               const unsigned long long* __restrict__ drop_epoch) {
-  const unsigned long long drop_seed = drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull;
+  const DropKey dkey = drop_key(drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull, drop_p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c0 = (blockIdx.x * 4 + w) * 32;
   if (c0 >= N) return;
@@ -271,13 +277,14 @@ __global__ __launch_bounds__(256) void lowrank_update_kernel(bf16_t* __restrict_
       }
       if (row < r1 && cok) {
         bf16x8 o;
+        // dropout on the LoRA branch (utils/lora.py:49,119): same mask protocol as the GEMM epilogue
+        const unsigned kb = drop_p > 0.f ? drop_bits8(dkey, (unsigned long long)row * N + ccol) : 0xffu;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float u0 = scale * acc0[e], u1 = scale * acc1[e];
-          if (drop_p > 0.f) {       // dropout on the LoRA branch (utils/lora.py:49,119): same mask protocol as the GEMM epilogue
-            const unsigned long long idx = (unsigned long long)row * N + ccol + e;
-            u0 = drop_keep(drop_seed, idx, drop_p) ? u0 * ks_keep : 0.f;
-            u1 = drop_keep(drop_seed, idx + 4, drop_p) ? u1 * ks_keep : 0.f;
+          if (drop_p > 0.f) {
+            u0 = ((kb >> e) & 1u) ? u0 * ks_keep : 0.f;
+            u1 = ((kb >> (4 + e)) & 1u) ? u1 * ks_keep : 0.f;
           }
           o[e] = (short)f2bf(bf2f((unsigned short)yv[u][e]) + u0);
           o[4 + e] = (short)f2bf(bf2f((unsigned short)yv[u][4 + e]) + u1);
@@ -483,7 +490,8 @@ extern "C" int t2v_set_dropout_epoch(const unsigned long long* device_counter) {
 extern "C" int t2v_dropout_mask(const void* x, long long ldx, void* y, long long ldy, long long rows, int cols, float p,
                                 unsigned long long seed, t2v_stream_t s) {
   T2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && p >= 0.f && p < 1.f, "t2v_dropout_mask: bad args");
-  LAUNCH1D(dropout_mask_kernel, rows * cols, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, p, seed, t2v_drop_epoch);
+  T2V_CHECK_ARG(cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "t2v_dropout_mask: cols and the leading dimensions must be multiples of 8");
+  LAUNCH1D(dropout_mask_kernel, rows * (cols / 8), s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, p, seed, t2v_drop_epoch);
 }
 static int lowrank_update_impl(void* y, long long ldy, const void* t, long long ldt, const void* U, long long ldu, long long M,
                                int N, int r, float scale, float drop_p, unsigned long long drop_seed, t2v_stream_t s) {

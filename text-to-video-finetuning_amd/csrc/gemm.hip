@@ -80,12 +80,10 @@ __device__ __forceinline__ void finish_chunk(const T2VGemm& p, float (&v)[8], lo
       break;
     }
     if (p.drop_p > 0.f) {
-      const unsigned long long seed = eff_seed(p.drop_seed, p.drop_epoch);
+      const DropKey dkey = drop_key(eff_seed(p.drop_seed, p.drop_epoch), p.drop_p);
+      const unsigned kb = drop_bits8(dkey, ((unsigned long long)z * M + row) * N + col);     // (col % 8 == 0, N % 8 == 0: check_gemm)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        unsigned long long idx = ((unsigned long long)z * M + row) * N + col + e;
-        v[e] = drop_keep(seed, idx, p.drop_p) ? v[e] * keep_scale : 0.f;
-      }
+      for (int e = 0; e < 8; ++e) v[e] = ((kb >> e) & 1u) ? v[e] * keep_scale : 0.f;
     }
     if (bias) {
       if (full) {

@@ -31,6 +31,11 @@ struct Prob {
   float* out;
   long long ldo;
   int tiles;
+  // dropout mask on the wide operand (the dU problem of a layer whose LoRA branch is dropped: Big = mask (.) dy / (1-p),
+  // utils/lora.py:49,119; the mask is regenerated from (seed, row * C + column), never stored): mp > 0 switches it on
+  float mp;
+  unsigned long long mseed;
+  const unsigned long long* mepoch;
 };
 
 struct Args {
@@ -55,6 +60,9 @@ __device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, lon
   for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 rb[2], rs[NS];
+  const bool masked = P.mp > 0.f;
+  const DropKey dkey = drop_key(masked ? eff_seed(P.mseed, P.mepoch) : 0ull, P.mp);
+  if (masked) alpha *= 1.f / (1.f - P.mp);         // the kept elements' 1/(1-p) rides in the output scale: the operand is a bit select
   const int srow = (tid & 127) >> 1, shalf = tid & 1, stap0 = tid >> 7;
   const unsigned hw = (unsigned)(g.Hv * g.Wv);
 
@@ -65,6 +73,12 @@ __device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, lon
       const long long gr = row0 + row;
       const int col = c0 + cc * 8;
       rb[i] = (gr < r_end && col < P.C) ? *(const bf16x8*)(P.big + gr * P.ldbig + col) : zero8;
+      if (masked && gr < r_end && col < P.C) {
+        const unsigned kb = drop_bits8(dkey, (unsigned long long)gr * P.C + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!((kb >> e) & 1u)) rb[i][e] = 0;
+      }
     }
     const long long q = row0 + srow;
     const bool okq = q < r_end && shalf * 8 < rk;
@@ -144,6 +158,107 @@ __device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, lon
   }
 }
 
+
+// ---- dt = (mask (.) dy) U^T / (1-p): the gradient of the down-projection output of a layer whose LoRA branch is dropped
+// (utils/lora.py:49,119: y = base(x) + scale * dropout(up(down(x))), so d(up input) = (mask (.) dy / (1-p)) U).  One streaming
+// pass over dy: the mask is regenerated from (seed, row * N + column) and applied as a bit select on the loaded chunk, no masked
+// copy of dy is ever written (round 3: a mask pass (read + write) plus a skinny GEMM (read) = three passes and two launches).
+// v_mfma_f32_16x16x32_bf16 with A = 16 rows x 32 columns of dy, B = the same 32 columns of 16 rank rows of U; the contraction
+// index is permuted so that a lane reads 2 x 16 contiguous bytes of its row (k group g <-> columns 16g .. 16g+15 of a 64-column
+// block, MFMA step s takes the s-th 8).  Workgroup = 4 waves as WR x WC: a wave owns 32 rows (two row groups) and every WC-th
+// 64-column block; with WC > 1 the partial sums meet in LDS.
+template <int RG>      // rank groups of 16
+__global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ U,
+                                                            long long ldu, bf16_t* __restrict__ dt, long long lddt, long long M, int N,
+                                                            int rp, int WC, float p, unsigned long long seed_in,
+                                                            const unsigned long long* __restrict__ epoch) {
+  __shared__ float red[4][32][RG * 16 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int WR = 4 / WC, wr = w / WC, wc = w - wr * WC;
+  const int li = lane & 15, g4 = lane >> 4;
+  const long long row0 = ((long long)blockIdx.x * WR + wr) * 32;
+  const DropKey dkey = drop_key(eff_seed(seed_in, epoch), p);
+  const float ks = 1.f / (1.f - p);
+  f32x4 acc[2][RG];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < RG; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int nblk = (N + 63) >> 6;
+  constexpr int UNR = 2;                           // 64-column blocks in flight per wave
+  for (int b0 = wc; b0 < nblk; b0 += WC * UNR) {
+    bf16x8 a[UNR][2][2], u[UNR][RG][2];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      const int col = (b0 + q * WC) * 64 + g4 * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bool cok = (b0 + q * WC) < nblk && col + s * 8 < N;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+          const long long row = row0 + rg * 16 + li;
+          a[q][rg][s] = (cok && row < M) ? *(const bf16x8*)(dy + row * lddy + col + s * 8) : zero8;
+        }
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+          const int rk = j * 16 + li;
+          u[q][j][s] = (cok && rk < rp) ? *(const bf16x8*)(U + (long long)rk * ldu + col + s * 8) : zero8;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      const int col = (b0 + q * WC) * 64 + g4 * 16;
+      if ((b0 + q * WC) >= nblk) break;             // wave-uniform
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+          const long long row = row0 + rg * 16 + li;
+          bf16x8 g = a[q][rg][s];
+          if (row < M && col + s * 8 < N) {
+            const unsigned kb = drop_bits8(dkey, (unsigned long long)row * N + col + s * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (!((kb >> e) & 1u)) g[e] = 0;
+          }
+#pragma unroll
+          for (int j = 0; j < RG; ++j) acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, u[q][j][s], acc[rg][j], 0, 0, 0);
+        }
+    }
+  }
+  // accumulator: lane holds rows 4*g4 + r (r = 0..3) of the row group, rank 16j + li
+  if (WC == 1) {
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int j = 0; j < RG; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long row = row0 + rg * 16 + 4 * g4 + r;
+          const int rk = j * 16 + li;
+          if (row < M && rk < rp) dt[row * lddt + rk] = f2bf(acc[rg][j][r] * ks);
+        }
+    return;
+  }
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int j = 0; j < RG; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][rg * 16 + 4 * g4 + r][j * 16 + li] = acc[rg][j][r];
+  __syncthreads();
+  // WR row bands of 32 rows x (RG*16) ranks, each summed over its WC waves in wave order
+  for (int i = tid; i < WR * 32 * RG * 16; i += 256) {
+    const int rk = i % (RG * 16), rr = (i / (RG * 16)) % 32, band = i / (RG * 16 * 32);
+    float v = 0.f;
+    for (int c = 0; c < WC; ++c) v += red[band * WC + c][rr][rk];
+    const long long row = ((long long)blockIdx.x * WR + band) * 32 + rr;
+    if (row < M && rk < rp) dt[row * lddt + rk] = f2bf(v * ks);
+  }
+}
+
 template <int TAPS_D>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[KR * PITCH + TAPS_D * KR * SP];
@@ -191,6 +306,7 @@ __global__ __launch_bounds__(256) void lora_wgrad_batch_kernel(const Args* __res
 int wgrad_passes(const T2VLoraWgrad& p, Args* out, int* blocks) {
   T2V_CHECK_ARG(p.rows > 0 && p.rows < (1LL << 31) && p.t && p.dy && p.dU && p.dt && p.x && p.dD, "t2v_lora_wgrad: bad args");
   T2V_CHECK_ARG(p.rp >= 8 && p.rp <= 32 && p.rp % 8 == 0, "t2v_lora_wgrad: padded rank must be 8, 16, 24 or 32 (got %d)", p.rp);
+  T2V_CHECK_ARG(p.drop_p >= 0.f && p.drop_p < 1.f, "t2v_lora_wgrad: dropout probability must be in [0, 1)");
   T2V_CHECK_ARG(p.N > 0 && p.N % 8 == 0 && p.C > 0 && p.C % 8 == 0 && p.ldt % 8 == 0 && p.lddt % 8 == 0 && p.lddy % 8 == 0 &&
                     p.ldx % 8 == 0,
                 "t2v_lora_wgrad: N, C and the bf16 leading dimensions must be multiples of 8 (N=%d C=%d)", p.N, p.C);
@@ -211,8 +327,10 @@ int wgrad_passes(const T2VLoraWgrad& p, Args* out, int* blocks) {
   for (int r0 = 0; r0 < p.rp; r0 += 16, ++n) {     // one pass per 16 rank rows
     Args& a = out[n];
     a.rk = std::min(16, p.rp - r0);
-    a.u = Prob{(const bf16_t*)p.dy, p.lddy, p.N, (const bf16_t*)p.t + r0, p.ldt, p.dU + (long long)r0 * p.lddu, p.lddu, (p.N + 63) / 64};
-    a.d = Prob{(const bf16_t*)p.x, p.ldx, p.C, (const bf16_t*)p.dt + r0, p.lddt, p.dD + (long long)r0 * p.lddd, p.lddd, (p.C + 63) / 64};
+    a.u = Prob{(const bf16_t*)p.dy, p.lddy, p.N, (const bf16_t*)p.t + r0, p.ldt, p.dU + (long long)r0 * p.lddu, p.lddu, (p.N + 63) / 64,
+               p.drop_p, p.drop_seed, p.drop_p > 0.f ? t2v_drop_epoch : nullptr};
+    a.d = Prob{(const bf16_t*)p.x, p.ldx, p.C, (const bf16_t*)p.dt + r0, p.lddt, p.dD + (long long)r0 * p.lddd, p.lddd, (p.C + 63) / 64,
+               0.f, 0ull, nullptr};
     a.rows = p.rows;
     a.conv = p.conv;
     a.g = g;
@@ -283,5 +401,39 @@ extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
       T2V_LAUNCH(lora_wgrad_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, a);
     T2V_CHECK_LAUNCH();
   }
+  return T2V_OK;
+}
+
+extern "C" int t2v_lora_drop_dt(const void* dy, long long lddy, const void* U, long long ldu, void* dt, long long lddt, long long M,
+                                int N, int rp, float drop_p, unsigned long long drop_seed, t2v_stream_t stream) {
+  T2V_CHECK_ARG(dy && U && dt && M > 0 && N > 0 && N % 8 == 0 && lddy % 8 == 0 && ldu % 8 == 0 && lddt >= rp, "t2v_lora_drop_dt: bad args");
+  T2V_CHECK_ARG(rp >= 8 && rp <= 32 && rp % 8 == 0, "t2v_lora_drop_dt: padded rank must be 8, 16, 24 or 32 (got %d)", rp);
+  T2V_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "t2v_lora_drop_dt: dropout probability must be in [0, 1)");
+  // waves as WR x WC: split the columns over WC waves when the rows alone give too few workgroups, prefer the split that wastes
+  // the fewest 64-column blocks
+  const int nblk = (N + 63) / 64;
+  int best_wc = 1;
+  double best = 1e30;
+  for (int wc : {1, 2, 4}) {
+    const long long blocks = (M + 32 * (4 / wc) - 1) / (32 * (4 / wc));
+    const int per = (nblk + wc - 1) / wc;
+    const double waste = (double)per * wc / nblk;
+    const double fill = blocks >= 512 ? 1.0 : 512.0 / (double)blocks;       // under-filled launches: time ~ 1 / blocks
+    const double cost = waste * fill * (wc > 1 ? 1.05 : 1.0);
+    if (cost < best) {
+      best = cost;
+      best_wc = wc;
+    }
+  }
+  const int WR = 4 / best_wc;
+  const long long blocks = (M + 32 * WR - 1) / (32 * WR);
+  T2V_CHECK_ARG(blocks < (1LL << 31), "t2v_lora_drop_dt: too many rows");
+  if (rp <= 16)
+    T2V_LAUNCH(lora_drop_dt_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)U, ldu,
+               (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, drop_seed, t2v_drop_epoch);
+  else
+    T2V_LAUNCH(lora_drop_dt_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)U, ldu,
+               (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, drop_seed, t2v_drop_epoch);
+  T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                                                         unsigned* __restrict__ counters) {
   __shared__ float sval[256 * 17];
   __shared__ int s_last;   // per-thread (8 sums, 8 second sums), row stride 17 to dodge bank conflicts
-  const unsigned long long drop_seed = drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull;
+  const DropKey dkey = drop_key(drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull, drop_p);
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -89,11 +89,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
             }
           } else {
             const bf16x8 gv = gq[u];
+            const unsigned kb = drop_p > 0.f ? drop_bits8(dkey, (unsigned long long)row * C + cc * 8) : 0xffu;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
               float dz = bf2f((unsigned short)gv[e]);
-              if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + cc * 8 + e, drop_p) ? dz * ks : 0.f;
+              if (drop_p > 0.f) dz = ((kb >> e) & 1u) ? dz * ks : 0.f;
               if (silu) {
                 float zz = xh * gm[e] + bt[e];
                 float sg = sigmoid_f(zz);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                         float eps, int silu, float drop_p, unsigned long long drop_seed_in,
                                                         const unsigned long long* __restrict__ drop_epoch,
                                                         const bf16_t* __restrict__ addend, long long ldadd) {
-  const unsigned long long drop_seed = drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull;
+  const DropKey dkey = drop_key(drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull, drop_p);
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -272,19 +273,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         if (rr >= rend) continue;
         const long long row = base + rr;
         bf16x8 ov;
+        const unsigned kb = drop_p > 0.f ? drop_bits8(dkey, (unsigned long long)row * C + cc * 8) : 0xffu;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int c = cc * 8 + e;
           float out;
           if (!BWD) {
             float zz = bf2f((unsigned short)xv[u][e]) * gm[e] + bt[e];
             if (silu) zz = silu_f(zz);
-            if (drop_p > 0.f) zz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? zz * ks : 0.f;
+            if (drop_p > 0.f) zz = ((kb >> e) & 1u) ? zz * ks : 0.f;
             out = zz;
           } else {
             const float xh = (bf2f((unsigned short)xv[u][e]) - mu[e]) * rs[e];
             float dz = bf2f((unsigned short)gv[u][e]);
-            if (drop_p > 0.f) dz = drop_keep(drop_seed, (unsigned long long)row * C + c, drop_p) ? dz * ks : 0.f;
+            if (drop_p > 0.f) dz = ((kb >> e) & 1u) ? dz * ks : 0.f;
             if (silu) {
               const float zz = xh * gm[e] + bt[e];
               const float sg = sigmoid_f(zz);

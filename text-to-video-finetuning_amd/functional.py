@@ -622,14 +622,22 @@ class _LoraLayer(torch.autograd.Function):
             drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
         cin_p = e.cin_p
         need_dx = ctx.needs_input_grad[0]
-        g = dy                                       # gradient of the LoRA branch output: mask dy / (1-p) with dropout on
-        if drop_p > 0.0:
+        # gradient of the LoRA branch output: g = mask dy / (1-p) with dropout on.  It is never materialised when the streaming
+        # kernels apply: dt = g U comes from one masked pass over dy (t2v_lora_drop_dt) and the dU contraction regenerates the
+        # mask itself (T2VLoraWgrad.drop_p) — round 3 wrote g (mask pass) and read it twice.
+        g = dy
+        stream_ok = e.rp <= 32 and x.shape[0] == M and (not conv or _wgrad_window_ok(cfg.fwd_geom(e.cin_p), M))
+        fused_mask = drop_p > 0.0 and stream_ok and _drop_fuse
+        if drop_p > 0.0 and not fused_mask:
             g = torch.empty_like(dy)
             launch_gemm_dropmask(dy, g, drop_p, drop_seed)
         dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)      # dt = g U (unscaled; `scale` is applied by its consumers)
         dx = None
         ride = drop_p == 0.0                         # dt can ride in the dx launch only when both read the same dy
-        if not ride:
+        if fused_mask:
+            nv.call("t2v_lora_drop_dt", dy.data_ptr(), _ld(dy), e.up_w16.data_ptr(), _ld(e.up_w16), dt.data_ptr(), e.rp, M, npad,
+                    e.rp, drop_p, drop_seed, nv.stream())
+        elif not ride:
             launch_gemm(M=M, N=e.rp, K=npad, A=g.data_ptr(), lda=_ld(g), B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16),
                         D=dt.data_ptr(), ldd=e.rp)
         b2 = dict(B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp) if ride else {}
@@ -674,11 +682,15 @@ class _LoraLayer(torch.autograd.Function):
                 else:
                     dx = dxv
         # factor gradients dU = s t^T g, dD = s dt^T x, accumulated in the flat fp32 gradient buffer (side stream)
-        _lora_side_grads(x, g.data_ptr(), _ld(g), [g, dy, x, t, dt], cfg, e, scale, M, npad, cin_p, t=t, dt=dt)
+        _lora_side_grads(x, g.data_ptr(), _ld(g), [g, dy, x, t, dt], cfg, e, scale, M, npad, cin_p, t=t, dt=dt,
+                         drop=(drop_p, drop_seed) if fused_mask else None)
         return dx, None, None, None, None, drb, dres, None, None, None, None, None
 
 
-def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=None, dt=None):
+_drop_fuse = os.environ.get("T2V_DROP_FUSE", "1") != "0"       # A/B switch: masks regenerated inside the backward kernels
+
+
+def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=None, dt=None, drop=None):
     """Factor gradients of one merged layer on the side stream: dU += s t^T dy, dD += s dt^T x (streaming kernel; strided /
     resampled windows: two K-major GEMMs in one launch).  `t = x (*) D^T` normally rides in the forward launch and
     `dt = dy U` in the backward-data launch (rank columns of those launches); whichever is missing is formed here by a
@@ -707,8 +719,11 @@ def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=Non
             if conv:
                 w.geom = g
             w.alpha = scale
+            if drop is not None:  # `dy_ptr` is the unmasked gradient: the dU contraction applies the branch's dropout mask itself
+                w.drop_p, w.drop_seed = drop
             _wgrad_launch(w, (tt, dtt, x, keep))
         else:                     # strided / resampled windows: two K-major GEMMs in one launch
+            assert drop is None
             launch_gemm_pair(
                 dict(M=e.rp, N=npad, K=M, A=tt.data_ptr(), lda=_ld(tt), a_trans=1, B=dy_ptr, ldb=lddy, b_trans=1,
                      D=e.up_g.data_ptr(), ldd=_ld(e.up_g), out_mode=nv.OUT_F32_ATOMIC, alpha=scale,

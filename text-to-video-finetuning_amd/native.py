@@ -28,7 +28,7 @@ class LoraWgrad(C.Structure):
         ("t", c_void_p), ("ldt", c_ll), ("dy", c_void_p), ("lddy", c_ll), ("N", c_int),
         ("dU", c_void_p), ("lddu", c_ll), ("dt", c_void_p), ("lddt", c_ll),
         ("x", c_void_p), ("ldx", c_ll), ("C", c_int), ("dD", c_void_p), ("lddd", c_ll),
-        ("geom", ConvGeom), ("alpha", c_float),
+        ("geom", ConvGeom), ("alpha", c_float), ("drop_p", c_float), ("drop_seed", c_ull),
     ]
 
 
@@ -88,7 +88,7 @@ class Attn(C.Structure):
     ]
 
 
-ABI_VERSION = 3          # include/t2v_abi.h T2V_ABI_VERSION
+ABI_VERSION = 4          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
@@ -129,6 +129,7 @@ SYMBOLS = {
     "t2v_lowrank_update_drop": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_float, c_ull,
                                  c_void_p], c_int),
     "t2v_lora_wgrad": ([C.POINTER(LoraWgrad), c_void_p], c_int),
+    "t2v_lora_drop_dt": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_lora_wgrad_batch_bytes": ([c_int], c_ll),
     "t2v_lora_wgrad_batch": ([C.POINTER(LoraWgrad), c_int, c_void_p, c_void_p, c_ll, c_void_p], c_int),
     "t2v_lowrank_window_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, C.POINTER(ConvGeom), c_ll, c_int, c_int,
