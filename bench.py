@@ -53,14 +53,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (median is reported; one untimed warm-up first)")
-    ap.add_argument("--dropout", action="store_true",
-                    help="the reference's default train mode: LoRA dropout 0.1 (utils/lora.py:35,89) and TemporalConvLayer "
-                         "dropout 0.1 (models/unet_3d_blocks.py:312) instead of its eval_train mode; eager launches")
+    ap.add_argument("--no-cpu-c2", action="store_true", help="skip the single timed CPU-oracle step at the C2 clip (SURVEY 8(d): C1 x3 and C2 once)")
+    ap.add_argument("--eval-train", action="store_true",
+                    help="the reference's OPT-IN eval_train mode (train.py:779-781: every Dropout off) instead of its default train "
+                         "mode, which is what the headline measures: LoRA dropout 0.1 (utils/lora.py:35,89; lora_unet_dropout 0.1 in "
+                         "every shipped YAML) and TemporalConvLayer dropout 0.1 (models/unet_3d_blocks.py:312)")
+    ap.add_argument("--dropout", action="store_true", help="(default since round 4; kept so that older command lines still parse)")
     ap.add_argument("--grad-checkpointing", action="store_true", help="train.py:127-129,670-675")
     ap.add_argument("--no-text-encoder", action="store_true", help="feed synthetic text states instead of running CLIP")
-    ap.add_argument("--no-default-mode", action="store_true",
-                    help="skip the extra short run in the reference's default train mode (dropout on) that fills "
-                         "config.default_mode_ms_per_step")
+    ap.add_argument("--no-default-mode", "--no-other-mode", dest="no_default_mode", action="store_true",
+                    help="skip the extra short run in the OTHER dropout mode (eval_train beside the default-mode headline, or the "
+                         "default mode beside an --eval-train line) that fills config.eval_train_ms_per_step / default_mode_ms_per_step")
     ap.add_argument("--export-tune-table", default=None,
                     help="write the GEMM tile table after the run (use with T2V_GEMM_AUTOTUNE=live; scripts/tune_gemm_table.sh)")
     return ap.parse_args()
@@ -196,6 +199,9 @@ def gemm_roofline(trainer, batch):
         ret, s, e, inner = run_timed(lambda: orig(cs=cs, **kw))
         z = max(1, kw.get("batch", 1))
         flops = 2.0 * kw["M"] * kw["N"] * kw["K"] * z
+        lr_ = kw.get("lr")
+        if lr_ is not None:      # rank-wide epilogue term of the launch (dropped LoRA branch): t = x D^T once + the rank-wide product
+            flops += 2.0 * kw["M"] * lr_["rp"] * (kw["N"] * lr_.get("taps", 1) + (kw["K"] if lr_["mode"] == 2 else 0))
         geom = kw.get("geom")
         if geom is not None and geom.tdiv == 2:
             flops /= 4.0                                 # 3/4 of the gathered taps are structural zeros
@@ -438,7 +444,7 @@ def rocprof_family_time(algorithmic_flops):
         return None
 
 
-def cpu_baseline(steps, device):
+def cpu_baseline(steps, device, c2_once=True):
     """The CPU oracle (restatement of the reference path; the reference itself needs diffusers, absent offline) timed on
     the host cores: full train steps of config C1 (8 frames @128x128, LoRA r=4, batch 1), one untimed warm-up, then the
     MEDIAN of `steps` timed steps.  The first (warm-up) step doubles as the in-run parity check: the native trainer
@@ -508,13 +514,23 @@ def cpu_baseline(steps, device):
             t0 = time.time()
             train_step(unet, vae, b, opt)
             times.append(time.time() - t0)
+        c2_s = None
+        if c2_once:             # the C2 clip once (same oracle objects: LoRA r=4 instead of 16 changes < 0.1 % of the work)
+            f2, H2, W2, _ = CONFIGS["c2"]
+            b2 = obatch(f2, H2, W2, seed=3000)
+            t0 = time.time()
+            train_step(unet, vae, b2, opt)
+            c2_s = time.time() - t0
     if l_gpu is not None:
         rel = abs(l_gpu - l_cpu) / abs(l_cpu)
     med = statistics.median(times)
     return dict(value=1.0 / med, unit="videos/s", cores=cores, kind="port",
                 sample=f"median of {steps} full train steps of config C1 (8 frames @128x128, LoRA r=4, fp32, PyTorch CPU oracle on "
                        f"{cores} threads, temporal Conv3d run as conv2d) after one warm-up step: {med:.2f} s/step "
-                       f"(all: {', '.join(f'{t:.1f}' for t in times)}); a C1 clip is ~1/8 of the C2 clip's work",
+                       f"(all: {', '.join(f'{t:.1f}' for t in times)})"
+                       + (f"; ONE full train step at the C2 clip (16 frames @256x256) on the same threads: {c2_s:.1f} s = "
+                          f"{1.0 / c2_s:.4f} videos/s" if c2_s else "; a C1 clip is ~1/8 of the C2 clip's work"),
+                c2_step_s=(round(c2_s, 2) if c2_s else None), c2_videos_per_s=(round(1.0 / c2_s, 5) if c2_s else None),
                 eps_mse_rel_err=rel, eps_mse_cpu=l_cpu, eps_mse_gpu=l_gpu,
                 eps_mse_note="same seeded ModelScope-1.7B weights (lora_up ~ N(0, 0.02^2): live LoRA branches) and C1 batch: native "
                              "trainer loss on the GPU vs the CPU fp32 oracle, this run; full-size C1/C2 loss + every factor gradient "
@@ -550,6 +566,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     frames, H, W, r = CONFIGS[args.config]
+    args.dropout = not args.eval_train          # headline = the mode train.py drives by default (train.py:779: eval_train=False)
 
     unet, vae, trainable = build_models(frames, r, dev, seed=0, dropout=args.dropout,
                                         grad_ckpt=args.grad_checkpointing)   # same frozen weights on every rank
@@ -621,11 +638,12 @@ def main():
     final_loss = float(loss.item())
 
     default_mode_ms = None
-    if (rank == 0 and world == 1 and args.config == "c2" and not args.dropout and not args.no_default_mode and use_graph):
-        # the reference's DEFAULT train mode (LoRA dropout 0.1, utils/lora.py:35,89; TemporalConvLayer dropout 0.1,
-        # models/unet_3d_blocks.py:312) on the same clip: a short graph-replayed run beside the headline (eval_train) line
+    if (rank == 0 and world == 1 and args.config == "c2" and not args.no_default_mode and use_graph):
+        # the OTHER dropout mode on the same clip, a short graph-replayed run beside the headline: the reference's opt-in
+        # eval_train mode (train.py:779-781, every Dropout off -> LoRA branches merged into the weights) beside the default-mode
+        # headline, or the default mode beside an --eval-train line
         try:
-            d_unet, d_vae, d_train = build_models(frames, r, dev, seed=0, dropout=True, grad_ckpt=args.grad_checkpointing)
+            d_unet, d_vae, d_train = build_models(frames, r, dev, seed=0, dropout=not args.dropout, grad_ckpt=args.grad_checkpointing)
             d_tr = DenoiseTrainer(d_unet, d_vae, d_train, lr=5e-6, world_size=1, text_encoder=text_encoder)
             d_batch = synthetic_batch(frames, H, W, dev, seed=1234, with_ids=text_encoder is not None)
             d_tr.capture(d_batch, warmup=1)
@@ -671,7 +689,7 @@ def main():
                     north_star_kernels=both["north_star"])
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_steps, dev)
+        cpu = cpu_baseline(args.cpu_steps, dev, c2_once=not args.no_cpu_c2)
 
     if rank == 0:
         out = {
@@ -693,9 +711,12 @@ def main():
                        "flat_gradient_elems": trainer.opt.numel, "final_loss": final_loss,
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                        "eps_mse_rel_err": (cpu or {}).get("eps_mse_rel_err"),
-                       "default_mode_ms_per_step": default_mode_ms,
-                       "default_mode_note": "same clip in the reference's default train mode (LoRA dropout 0.1 + TemporalConvLayer dropout "
-                                            "0.1, masks restated in oracle/dropout.py), 10 graph replays" if default_mode_ms else None,
+                       "default_mode_ms_per_step": (round(dt / args.steps * 1e3, 2) if args.dropout else default_mode_ms),
+                       "eval_train_ms_per_step": (default_mode_ms if args.dropout else round(dt / args.steps * 1e3, 2)),
+                       "mode_note": "headline = the reference's DEFAULT train mode (LoRA dropout 0.1 + TemporalConvLayer dropout 0.1, masks "
+                                    "restated in oracle/dropout.py); eval_train_ms_per_step = the same clip with every Dropout off "
+                                    "(train.py:779-781 opt-in), 10 graph replays" if args.dropout else
+                                    "--eval-train line; default_mode_ms_per_step = the same clip in the reference's default mode, 10 graph replays",
                        "host_ms_per_step": host_ms},
             "roofline": roof, "cpu_baseline": cpu,
         }

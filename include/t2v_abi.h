@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 4   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
+#define T2V_ABI_VERSION 5   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -121,11 +121,33 @@ typedef struct {
   float* colsum; int cs_mode; int cs_domain_rows;
   const void* cs_x; long long cs_ldx; const float* cs_sums; const float* cs_gamma; const float* cs_beta; float cs_eps;
   int cs_G; int cs_silu;
+  /* ABI v5 — optional rank-wide epilogue term: the LoRA branch of a wrapped layer folded into the base layer's launch
+   * (utils/lora.py:57-62,134-139,211-216 and their autograd) when it cannot be merged into the weight, i.e. with the wrapper's
+   * dropout active (the reference's default train mode, utils/lora.py:35,49,89,119):
+   *   D[m, n] += lr_scale * mask(m, n) * sum_{tap, j} LA[src(m, tap), j] * LB[n, tap * lr_rk + j]
+   * LB = lr_b, bf16 [N, lr_ldb]: row n = output column, K ordered (tap, rank), lr_rk = 16 (lr_rp <= 16) or 32 ranks per tap,
+   * zero padded.  mask(m, n) = keep(lr_drop_seed, m * N + n) / (1 - lr_drop_p) of t2v_dropout_mask's protocol (1 when
+   * lr_drop_p == 0), regenerated in the epilogue.  Needs alpha == 1, bf16 output, and an 8-wave kernel (t2v_gemm selects one).
+   *   lr_mode 1: LA = lr_a, bf16 [rows, lr_lda], read from memory; lr_taps > 1: src(m, tap) = the source row `geom` (the A
+   *              gather's own stride-1 same-size window) gives for output row m under `tap`, zero outside — the backward-data
+   *              launch of a wrapped layer: dx = dy (*) W^T + s dt (*) D^T with dt = lr_a, LB = the flipped-tap transpose of D.
+   *   lr_mode 2: LA = x (*) B2^T computed BY THIS LAUNCH: every column tile carries the lr_rp rows of B2 (bf16 [lr_rp, ldb2],
+   *              the down factor in the layout of B) as extra weight rows behind its base columns; their accumulators t are
+   *              rounded to bf16, written to D2 [M, ldd2] (the saved down-projection of the backward) and multiplied with LB in
+   *              the epilogue: y = x W^T + s mask (t U^T) in one launch, with no pass over y.  N counts the base columns only;
+   *              n_split must be 0, lr_taps 1. */
+  int lr_mode; int lr_rp; int lr_taps;
+  const void* lr_a; long long lr_lda;
+  const void* lr_b; long long lr_ldb;
+  float lr_scale; float lr_drop_p; unsigned long long lr_drop_seed;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
 /* Tile rows BMt of the kernel t2v_gemm will run for this descriptor if that kernel can emit `colsum`, else 0 (deterministic:
  * shipped tile table / heuristic; 0 during live tuning runs). */
 int t2v_gemm_colsum_rows(const T2VGemm* p);
+/* 1 if t2v_gemm runs this descriptor WITH its rank-wide epilogue term (lr_mode != 0: the 8-wave kernels' domain — K%64, window
+ * C%64, bf16 output, 32-bit offsets), else 0: the caller then evaluates the LoRA branch with separate launches. */
+int t2v_gemm_lr_ok(const T2VGemm* p);
 /* Pinned launch on one of the 8-wave, one-workgroup-per-CU configurations of csrc/gemm_w8.hip (what t2v_gemm selects through
  * the tile table for lean descriptors: K%64==0, window C%64==0, bf16 output, no dropout / batch); for tuning runs, the
  * configuration probes (scripts/w8_probe.py) and the kernel tests.  cfg: configuration index (t2v_gemm_w8_configs() of them);
@@ -185,14 +207,17 @@ int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy, int ndoma
                  const float* sums, const float* gamma, const float* beta, float eps, int silu,
                  float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
 /* backward: bsums fp32 [ndomains,G,2] = (sum dxh, sum dxh*xh), written; dgamma/dbeta fp32 [C] accumulate (may be NULL).
- * With dgamma/dbeta set (full finetune) the launch is followed by a fixed-order reduction of per-workgroup partial rows that
- * live in a LIBRARY-OWNED device scratch (one per device, allocated with hipMalloc on first use / growth: the first call of a
- * given size must therefore happen outside a stream capture — a warm-up step does that).  Same for t2v_layernorm_bwd.
- * No float atomics: the parameter gradients are bit-reproducible. */
+ * With dgamma/dbeta set (full finetune) the launch is followed by a fixed-order reduction of per-workgroup partial rows held in
+ * `pg_workspace`: caller-owned fp32 scratch of t2v_gn_bwd_pg_floats(ndomains, rows_per_domain, C) elements (no initialisation
+ * needed; NULL when dgamma/dbeta are NULL) — like every other scratch of this ABI the library never allocates it (ABI v5; v3
+ * kept a library-owned hipMalloc buffer, whose first use inside a stream capture failed).  Same for t2v_layernorm_bwd with
+ * t2v_layernorm_bwd_pg_floats(rows, C).  No float atomics: the parameter gradients are bit-reproducible. */
+long long t2v_gn_bwd_pg_floats(int ndomains, int rows_per_domain, int C);
+long long t2v_layernorm_bwd_pg_floats(int rows, int C);
 int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long lddy, int ndomains, int rows_per_domain,
                      int C, int G, const float* sums, const float* gamma, const float* beta, float eps, int silu,
                      float drop_p, unsigned long long drop_seed,
-                     float* bsums, float* workspace, float* dgamma, float* dbeta, t2v_stream_t stream);
+                     float* bsums, float* workspace, float* dgamma, float* dbeta, float* pg_workspace, t2v_stream_t stream);
 int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
                      int ndomains, int rows_per_domain, int C, int G, const float* sums, const float* bsums,
                      const float* gamma, const float* beta, float eps, int silu,
@@ -205,8 +230,8 @@ int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, long long ldd
 int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int C, const float* gamma,
                       const float* beta, float eps, float* stats, t2v_stream_t stream);
 int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int rows,
-                      int C, const float* gamma, const float* stats, float* dgamma, float* dbeta, const void* addend,
-                      long long ldadd, t2v_stream_t stream);
+                      int C, const float* gamma, const float* stats, float* dgamma, float* dbeta, float* pg_workspace,
+                      const void* addend, long long ldadd, t2v_stream_t stream);
 
 /* ---- scaled-dot-product attention core, head_dim 64, no mask (AttnProcessor2_0, train.py:138-139).
  * One kernel serves temporal self (S=F, strided over frames), spatial self (S=H*W) and cross (Sk=77)
@@ -318,6 +343,23 @@ typedef struct T2VLoraMergeJob {
  * tile_job == NULL).  Returns the total tile count (grid size) or a negative error. */
 long long t2v_lora_merge_plan(T2VLoraMergeJob* jobs, int njobs, int* tile_job, long long capacity);
 int t2v_lora_merge(const T2VLoraMergeJob* jobs_dev, int njobs, const int* tile_job_dev, long long ntiles, t2v_stream_t stream);
+
+/* ---- transposed bf16 copies of the LoRA factors of all wrapped layers in ONE launch: the operands of the rank-wide epilogue
+ * term of t2v_gemm (T2VGemm.lr_b) when the wrappers' dropout is active and the branch cannot be merged into the weight.
+ *   upT[n, j]          = U[j, n]                              bf16 [Np, rk]        (forward: y += s mask (t U^T))
+ *   dnT[c, tap*rk + j] = scale * D[j, (taps-1-tap)*Cp + c]    bf16 [Cp, taps*rk]   (backward-data: dx += s dt (*) D^T)
+ * rk = 16 (rp <= 16) or 32, ranks >= rp zero.  Device pointers; the job table lives in device memory.  chunk0 = sum of
+ * t2v_lora_prep_chunks() of the jobs before this one. */
+typedef struct T2VLoraPrepJob {
+  const float* up;   long long ldu;   /* fp32 U[j, n] = up[j*ldu + n], j < rp */
+  const float* down;                  /* fp32 D[j, tap*Cp + c], j < rp */
+  void* upT; void* dnT;
+  int Np, Cp, taps, rp, rk;
+  float scale;
+  long long chunk0;
+} T2VLoraPrepJob;
+long long t2v_lora_prep_chunks(int Np, int Cp, int taps, int rk);
+int t2v_lora_prep(const T2VLoraPrepJob* jobs_dev, int njobs, long long total_chunks, t2v_stream_t stream);
 
 /* ---- elementwise ---- */
 /* GEGLU gate: y[m, j] = x[m, j] * gelu_erf(x[m, inner + j])  (FeedForward/GEGLU) */

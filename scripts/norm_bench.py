@@ -27,7 +27,7 @@ def gn(rows, C, nd, label):
     mk = lambda f: [(lambda q=q: f(*q)) for q in sets]
     bench(f"gn_stats      {label}", mk(lambda x, dy, y, dx, add, sums, bs: nv.call("t2v_gn_stats", x.data_ptr(), C, nd, rpd, C, G, sums.data_ptr(), ws.data_ptr(), s)), E)
     bench(f"gn_apply      {label}", mk(lambda x, dy, y, dx, add, sums, bs: nv.call("t2v_gn_apply", x.data_ptr(), C, y.data_ptr(), C, nd, rpd, C, G, sums.data_ptr(), gm.data_ptr(), bt.data_ptr(), 1e-5, 1, 0.0, 0, s)), 2 * E)
-    bench(f"gn_bwd_stats  {label}", mk(lambda x, dy, y, dx, add, sums, bs: nv.call("t2v_gn_bwd_stats", x.data_ptr(), C, dy.data_ptr(), C, nd, rpd, C, G, sums.data_ptr(), gm.data_ptr(), bt.data_ptr(), 1e-5, 1, 0.0, 0, bs.data_ptr(), ws.data_ptr(), None, None, s)), 2 * E)
+    bench(f"gn_bwd_stats  {label}", mk(lambda x, dy, y, dx, add, sums, bs: nv.call("t2v_gn_bwd_stats", x.data_ptr(), C, dy.data_ptr(), C, nd, rpd, C, G, sums.data_ptr(), gm.data_ptr(), bt.data_ptr(), 1e-5, 1, 0.0, 0, bs.data_ptr(), ws.data_ptr(), None, None, None, s)), 2 * E)
     bench(f"gn_bwd_apply  {label}", mk(lambda x, dy, y, dx, add, sums, bs: nv.call("t2v_gn_bwd_apply", x.data_ptr(), C, dy.data_ptr(), C, dx.data_ptr(), C, nd, rpd, C, G, sums.data_ptr(), bs.data_ptr(), gm.data_ptr(), bt.data_ptr(), 1e-5, 1, 0.0, 0, add.data_ptr(), C, s)), 4 * E)
 def ln(rows, C, label):
     sets = []
@@ -39,7 +39,7 @@ def ln(rows, C, label):
     gm = torch.ones(C, device='cuda'); bt = torch.zeros(C, device='cuda'); s = nv.stream(); E = rows * C * 2
     mk = lambda f: [(lambda q=q: f(*q)) for q in sets]
     bench(f"ln_fwd        {label}", mk(lambda x, dy, y, dx, add, st: nv.call("t2v_layernorm_fwd", x.data_ptr(), C, y.data_ptr(), C, rows, C, gm.data_ptr(), bt.data_ptr(), 1e-5, st.data_ptr(), s)), 2 * E)
-    bench(f"ln_bwd        {label}", mk(lambda x, dy, y, dx, add, st: nv.call("t2v_layernorm_bwd", x.data_ptr(), C, dy.data_ptr(), C, dx.data_ptr(), C, rows, C, gm.data_ptr(), st.data_ptr(), None, None, add.data_ptr(), C, s)), 4 * E)
+    bench(f"ln_bwd        {label}", mk(lambda x, dy, y, dx, add, st: nv.call("t2v_layernorm_bwd", x.data_ptr(), C, dy.data_ptr(), C, dx.data_ptr(), C, rows, C, gm.data_ptr(), st.data_ptr(), None, None, None, add.data_ptr(), C, s)), 4 * E)
 for rows, C in ((32768, 320), (8192, 640), (2048, 1280), (512, 1280)):
     gn(rows, C, 32, f"per-frame  rows={rows} C={C}")
     gn(rows, C, 2, f"temporal   rows={rows} C={C}")

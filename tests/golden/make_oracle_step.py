@@ -5,6 +5,7 @@
     python tests/golden/make_oracle_step.py --config c2 --scales 0.02
     python tests/golden/make_oracle_step.py --config c3            (full finetune: gradients of all 1.41 B UNet parameters)
     python tests/golden/make_oracle_step.py --config c1 --scales 0.02 --dropout   (default train mode, restated masks)
+    python tests/golden/make_oracle_step.py --config c2 --scales 0.02 --dropout   (the same at the benchmark configuration)
 
 For ModelScope-1.7B shapes with host-seeded weights/inputs (tests/parity_utils.py) the CPU fp32 oracle evaluates the
 eps-MSE of train.py:793-834 and its gradients w.r.t. all 1148 LoRA factors.  Recorded per fixture:
@@ -78,11 +79,12 @@ def main():
         batch = synthetic_batch(frames, H, W, seed=1234)
         if args.dropout:
             from oracle import dropout as odrop
-            assert args.config == "c1", "the two passes draw different masks: both are evaluated (C1 size)"
+            assert args.config in ("c1", "c2"), "the two passes draw different masks: both are evaluated (C2: ~25 min on 8 cores)"
             pu.enable_reference_dropout(unet)
             # first _fwd_bwd of a fresh trainer: device epoch = (rank << 32) + 2, host step 0 (tests/test_lora_grads_gpu.py)
             ctx = odrop.install_protocol(unet, pu.DROPOUT_BASE_SEED, step=0, epoch=2, batch=1, frames=frames, passes=2)
-        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config == "c2" and not args.dropout))
+        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config == "c2" and not args.dropout),
+                                               sequential_passes=(args.config == "c2" and args.dropout))
         if args.dropout:
             assert ctx["k"] == 1, "both passes must have run through the protocol"
         total = sum(float(g.double().pow(2).sum()) for g in grads.values()) ** 0.5

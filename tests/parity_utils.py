@@ -133,7 +133,7 @@ def weight_checksum(unet, vae):
     return acc
 
 
-def oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=False):
+def oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=False, sequential_passes=False):
     """eps-MSE of train.py:793-834 and its gradients w.r.t. every LoRA factor, on the CPU in fp32.
     `single_pass_doubled`: with a frozen text encoder the two passes of train.py:814-834 are identical computations, so
     L = 2 L0 and g = 2 g0 exactly; evaluating one pass halves the host memory of the full-size C2 run."""
@@ -150,6 +150,22 @@ def oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=False):
             noisy = scheduler.add_noise(latents, batch["noise"], batch["timesteps"], None)
             pred = unet(noisy, batch["timesteps"], encoder_hidden_states=batch["encoder_hidden_states"]).sample
             loss = 2.0 * torch.nn.functional.mse_loss(pred.float(), batch["noise"].float())
+        elif sequential_passes:
+            # the two passes of train.py:814-834 one after the other, each with its own backward (gradients add up in .grad): the
+            # same loss and gradients as `(mse0 + mse1).backward()` with a frozen text encoder, at half the host memory — the
+            # full-size C2 run WITH dropout (the passes draw different masks, so neither can stand in for the other)
+            with torch.no_grad():
+                latents = tensor_to_vae_latent(batch["pixel_values"], vae, batch["vae_eps"])
+            noisy = scheduler.add_noise(latents, batch["noise"], batch["timesteps"], None)
+            total = 0.0
+            for _ in range(2):
+                pred = unet(noisy, batch["timesteps"], encoder_hidden_states=batch["encoder_hidden_states"]).sample
+                li = torch.nn.functional.mse_loss(pred.float(), batch["noise"].float())
+                li.backward()
+                total += float(li.detach())
+                del pred, li
+            grads = {n: p.grad.detach().clone() for n, p in unet.named_parameters() if p.requires_grad}
+            return total, grads
         else:
             loss, _ = finetune_unet_loss(unet, vae, batch)
         loss.backward()

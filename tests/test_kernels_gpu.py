@@ -958,6 +958,147 @@ def test_w8_configurations_match_the_table_kernels(M, N, rc, K, taps, res):
     assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "split-K counters must be left zero"
 
 
+@pytest.mark.parametrize("M,N,K,taps,rp,res,p_drop", [(512, 320, 320, 1, 16, 1, 0.1), (1152, 640, 1920, 3, 16, 0, 0.1),
+                                                       (1152, 320, 2880, 9, 16, 1, 0.1), (300, 1280, 1280, 1, 32, 0, 0.25),
+                                                       (2048, 128, 1152, 9, 8, 0, 0.1), (256, 2560, 320, 1, 24, 0, 0.0)])
+def test_w8_rank_epilogue_term_forward(M, N, K, taps, rp, res, p_drop):
+    """T2VGemm.lr_mode 2 — the dropped LoRA branch inside the base layer's launch (utils/lora.py:57-62 with the dropout of :49):
+    y = x (*) W^T + bias + R + s mask (t U^T), t = bf16(x (*) D^T) computed by every column tile and saved to D2.  Against torch
+    fp32 on the bf16 operands with the protocol mask, over the LR configurations x column steps x K splits, with and without
+    column statistics (the staged epilogue)."""
+    import ctypes as C
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    from oracle.dropout import keep_mask
+    kw, d, _, keep = _w8_problem(M, N, 0, K, taps, res, seed=M + K + rp)
+    a, w, b, r = keep[0], keep[1], keep[2], keep[3]
+    g = torch.Generator().manual_seed(77 + rp)
+    rk = 16 if rp <= 16 else 32
+    Dw = _bf(torch.randn(rp, K, generator=g) * K ** -0.5).cuda()
+    UT = torch.zeros(N, rk); UT[:, :rp] = torch.randn(N, rp, generator=g) * 0.5
+    UT = _bf(UT).cuda()
+    t = torch.zeros(M, rp, dtype=torch.bfloat16, device="cuda")
+    s, seed = 0.7, 0x5EED1234
+    kw.update(B2=Dw.data_ptr(), ldb2=K, D2=t.data_ptr(), ldd2=rp,
+              lr=dict(mode=2, rp=rp, b=UT.data_ptr(), ldb=rk, scale=s, drop_p=p_drop, drop_seed=seed))
+    # reference: the same launch without the term, then the branch in fp32
+    kw0 = {k: v for k, v in kw.items() if k not in ("lr", "B2", "ldb2", "D2", "ldd2")}
+    kw0.update(B2=Dw.data_ptr(), ldb2=K, n_split=N, D2=t.data_ptr(), ldd2=rp, N=N + rp)
+    d.zero_()
+    nv.call("t2v_gemm", C.byref(F.make_gemm(**{**kw0, "R": None, "ldr": 0})), nv.stream())
+    torch.cuda.synchronize()
+    base32_src = None
+    # fp32 base from torch directly (the bf16-rounded launch output would double-round)
+    af = a.float().cpu()
+    if taps == 1:
+        cols = af
+    elif taps == 9:
+        side = int((M // 2) ** 0.5)
+        x4 = af.view(2, side, side, -1)
+        xp = torch.zeros(2, side + 2, side + 2, x4.shape[-1]); xp[:, 1:-1, 1:-1] = x4
+        cols = torch.cat([xp[:, ky:ky + side, kx:kx + side] for ky in range(3) for kx in range(3)], -1).reshape(M, -1)
+    else:
+        x4 = af.view(1, 4, M // 4, -1)
+        xp = torch.zeros(1, 6, M // 4, x4.shape[-1]); xp[:, 1:-1] = x4
+        cols = torch.cat([xp[:, ky:ky + 4] for ky in range(3)], -1).reshape(M, -1)
+    base = cols @ w.float().cpu().T + b.cpu()
+    tref = _bf(cols @ Dw.float().cpu().T)
+    m = keep_mask(seed, M, N, p_drop).float() / (1.0 - p_drop) if p_drop > 0 else torch.ones(M, N)
+    ref = base + (r.float().cpu() if res else 0) + s * m * (tref.float() @ UT.float().cpu()[:, :rp].T)
+    assert relerr(t, tref) < 1e-2          # (the unfused launch's t: same rounding point)
+    scale = float(ref.abs().max())
+    desc = F.make_gemm(**kw)
+    assert nv.lib().t2v_gemm_lr_ok(C.byref(desc)) == 1
+    for cfg in (12, 17, 21, 22, 14, 16, 19, 20):      # (14, 16, 19, 20: K-group configurations, rank phase after the groups met)
+        for nstep, splits in ((0, 1), (160, 1), (0, 2), (96, 3)):
+            d.zero_(); t.zero_()
+            nv.call("t2v_gemm_w8", C.byref(desc), cfg, nstep, splits, nv.stream())
+            torch.cuda.synchronize()
+            err = float((d.float().cpu() - ref).abs().max()) / scale
+            et = relerr(t, tref)
+            assert err < 1.2e-2 and et < 1e-2, (cfg, nstep, splits, err, et)
+    # through t2v_gemm (heuristic configuration), with the GroupNorm column statistics of the FINAL output
+    if N % 32 == 0 and M % 128 == 0:
+        d.zero_()
+        import os
+        os.environ["T2V_GEMM_FORCE_CFG"] = "117,10,1"     # a configuration whose staged epilogue can emit them with the term
+        try:
+            info = F.launch_gemm(cs={"mode": 1}, **kw)
+        finally:
+            del os.environ["T2V_GEMM_FORCE_CFG"]
+        assert info is not None
+        buf, bm, mm, nb = info
+        G, nd = 32, 1
+        sums = torch.empty(nd * G * 2, device="cuda"); refs = torch.empty_like(sums)
+        nv.call("t2v_gn_finish", buf.data_ptr(), nd, M, N, G, sums.data_ptr(), nv.stream())
+        ws = F._gn_workspace(nd, G, d.device)
+        nv.call("t2v_gn_stats", d.data_ptr(), N, nd, M, N, G, refs.data_ptr(), ws.data_ptr(), nv.stream())
+        torch.cuda.synchronize()
+        assert float((d.float().cpu() - ref).abs().max()) / scale < 1.2e-2
+        assert relerr(sums, refs) < 1e-5
+        d.zero_()                                          # and through whatever t2v_gemm selects on its own
+        F.launch_gemm(cs={"mode": 1}, **kw)
+        torch.cuda.synchronize()
+        assert float((d.float().cpu() - ref).abs().max()) / scale < 1.2e-2
+    ws = F._gemm_workspace()
+    assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "split-K counters must be left zero"
+
+
+@pytest.mark.parametrize("M,N,K,taps,rp,res,masked", [(512, 320, 320, 1, 16, 0, 0), (1152, 640, 1920, 3, 16, 0, 0),
+                                                       (1152, 320, 2880, 9, 16, 1, 0), (300, 1280, 1280, 1, 32, 0, 1),
+                                                       (2048, 128, 1152, 9, 8, 0, 0), (512, 640, 640, 1, 24, 1, 1)])
+def test_w8_rank_epilogue_term_from_memory(M, N, K, taps, rp, res, masked):
+    """T2VGemm.lr_mode 1 — D += sum_tap LA[src(m, tap)] LB[n, tap]^T with LA read from memory: the backward-data launch of a
+    wrapped layer (dx = dy (*) W^T + s dt (*) D^T: windowed, no mask) and the masked one-tap form."""
+    import ctypes as C
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    from oracle.dropout import keep_mask
+    kw, d, _, keep = _w8_problem(M, N, 0, K, taps, res, seed=M + K + rp + 1)
+    a, w, b, r = keep[0], keep[1], keep[2], keep[3]
+    g = torch.Generator().manual_seed(99 + rp)
+    rk = 16 if rp <= 16 else 32
+    LA = _bf(torch.randn(M, rp, generator=g)).cuda()
+    LB = torch.zeros(N, taps, rk); LB[:, :, :rp] = torch.randn(N, taps, rp, generator=g) * 0.3
+    LB = _bf(LB.reshape(N, taps * rk)).cuda()
+    p_drop, seed, s = (0.1, 0xC0FFEE, 0.6) if masked else (0.0, 0, 1.0)
+    kw.update(lr=dict(mode=1, rp=rp, taps=taps, a=LA.data_ptr(), lda=rp, b=LB.data_ptr(), ldb=taps * rk, scale=s, drop_p=p_drop,
+                      drop_seed=seed))
+    af, laf = a.float().cpu(), LA.float().cpu()
+
+    def gather(src):
+        if taps == 1:
+            return src
+        if taps == 9:
+            side = int((M // 2) ** 0.5)
+            x4 = src.view(2, side, side, -1)
+            xp = torch.zeros(2, side + 2, side + 2, x4.shape[-1]); xp[:, 1:-1, 1:-1] = x4
+            return torch.cat([xp[:, ky:ky + side, kx:kx + side] for ky in range(3) for kx in range(3)], -1).reshape(M, -1)
+        x4 = src.view(1, 4, M // 4, -1)
+        xp = torch.zeros(1, 6, M // 4, x4.shape[-1]); xp[:, 1:-1] = x4
+        return torch.cat([xp[:, ky:ky + 4] for ky in range(3)], -1).reshape(M, -1)
+
+    base = gather(af) @ w.float().cpu().T + b.cpu()
+    lbf = LB.float().cpu().view(N, taps, rk)[:, :, :rp].reshape(N, taps * rp)
+    term = gather(laf) @ lbf.T
+    m = keep_mask(seed, M, N, p_drop).float() / (1.0 - p_drop) if masked else 1.0
+    ref = base + (r.float().cpu() if res else 0) + s * m * term
+    scale = float(ref.abs().max())
+    desc = F.make_gemm(**kw)
+    assert nv.lib().t2v_gemm_lr_ok(C.byref(desc)) == 1
+    for cfg in (12, 17, 21, 22, 14, 16, 19, 20):
+        for nstep, splits in ((0, 1), (160, 1), (0, 2), (96, 3)):
+            d.zero_()
+            nv.call("t2v_gemm_w8", C.byref(desc), cfg, nstep, splits, nv.stream())
+            torch.cuda.synchronize()
+            err = float((d.float().cpu() - ref).abs().max()) / scale
+            assert err < 1.2e-2, (cfg, nstep, splits, err)
+    d.zero_()
+    nv.call("t2v_gemm", C.byref(desc), nv.stream())
+    torch.cuda.synchronize()
+    assert float((d.float().cpu() - ref).abs().max()) / scale < 1.2e-2
+
+
 @pytest.mark.parametrize("force", ["114,0,1", "113,0,1", "2,2,1", "0,0,1", "112,5,2"])
 @pytest.mark.parametrize("M,C_,K,taps,rpd,res", [(1024, 320, 960, 3, 256, 1), (2048, 640, 640, 1, 1024, 0), (512, 320, 2880, 9, 256, 1)])
 def test_gemm_epilogue_groupnorm_statistics(M, C_, K, taps, rpd, res, force):
@@ -1003,7 +1144,7 @@ def test_gemm_epilogue_groupnorm_statistics(M, C_, K, taps, rpd, res, force):
             nv.call("t2v_gn_finish", info[0].data_ptr(), nd, rpd, C_, G, bs.data_ptr(), nv.stream())
             bref = torch.empty_like(bs)
             nv.call("t2v_gn_bwd_stats", x.data_ptr(), C_, d.data_ptr(), C_, nd, rpd, C_, G, fs.data_ptr(), gamma.data_ptr(),
-                    beta.data_ptr(), 1e-5, silu, 0.0, 0, bref.data_ptr(), ws.data_ptr(), None, None, nv.stream())
+                    beta.data_ptr(), 1e-5, silu, 0.0, 0, bref.data_ptr(), ws.data_ptr(), None, None, None, nv.stream())
             torch.cuda.synchronize()
             assert relerr(bs, bref) < 1e-4, silu
     finally:

@@ -20,7 +20,7 @@ import parity_utils as pu
 
 pytestmark = pytest.mark.gpu
 FLOOR_FACTOR = 2.0
-RESULTS = os.path.join(os.path.dirname(pu.GOLDEN), "..", "gpurun_out", "parity_r03.jsonl")
+RESULTS = os.path.join(os.path.dirname(pu.GOLDEN), "..", "gpurun_out", "parity_r04.jsonl")
 
 
 def _floor(config, scale):
@@ -338,18 +338,21 @@ def test_c3_full_finetune_gradients_match_the_oracle_fixture():
     assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row
 
 
-def test_c1_default_train_mode_with_dropout_matches_the_oracle_fixture():
-    """The reference's DEFAULT train mode at FULL model size (config C1 clip): LoRA dropout 0.1 on all 574 wrappers +
-    TemporalConvLayer dropout 0.1, two passes with their own masks.  The fixture is the CPU fp32 oracle running the restated masks
-    of the native protocol (tests/golden/make_oracle_step.py --config c1 --scales 0.02 --dropout); compared: loss, the complete
-    sketch of every factor gradient, per-tensor norms, sampled tensors."""
+@pytest.mark.parametrize("config", ["c1", "c2"])
+def test_default_train_mode_with_dropout_matches_the_oracle_fixture(config):
+    """The reference's DEFAULT train mode at FULL model size — config C1 and the benchmark configuration C2 (16 frames @256x256,
+    r = 16: what `python bench.py` times): LoRA dropout 0.1 on the Linear / Conv2d wrappers + TemporalConvLayer dropout 0.1, two
+    passes with their own masks.  The fixtures are the CPU fp32 oracle running the restated masks of the native protocol
+    (tests/golden/make_oracle_step.py --config c1|c2 --scales 0.02 --dropout); compared: loss, the complete sketch of every factor
+    gradient, per-tensor norms, sampled tensors.  This is the path with the LoRA branch folded into the base launches' epilogues
+    (T2VGemm.lr_mode), the masked dt / dU kernels and the GroupNorm-epilogue dropout."""
     from oracle.weights import synthetic_batch
     from t2v_amd.models import leaves
     from t2v_amd.training import DenoiseTrainer
-    frames, H, W, r = pu.CONFIGS["c1"]
+    frames, H, W, r = pu.CONFIGS[config]
     scale = 0.02
     ounet, ovae, n = pu.build_oracle(True, r, scale)
-    path = pu.fixture_path("c1", scale, dropout=True)
+    path = pu.fixture_path(config, scale, dropout=True)
     assert os.path.exists(path), path
     fx = torch.load(path, weights_only=False)
     assert fx.get("dropout") and abs(pu.weight_checksum(ounet, ovae) - fx["checksum"]) <= 1e-6 * abs(fx["checksum"])
@@ -358,15 +361,16 @@ def test_c1_default_train_mode_with_dropout_matches_the_oracle_fixture():
     pu.enable_reference_dropout(dunet)
     leaves.set_dropout_seed(pu.DROPOUT_BASE_SEED)
     trainer = DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=5e-6)
+    assert trainer.opt.prep is not None and trainer.opt.prep.wanted()
     batch = synthetic_batch(frames, H, W, seed=1234)
     ld, gd = pu.native_loss_and_grads(trainer, dunet, batch)      # first step of a fresh trainer: epoch 2, host step 0
     sk_rel, worst_big, bad_norm, c = _compare_with_fixture(fx, gd)
-    row = dict(test="full_c1_dropout", scale=scale, loss_oracle=fx["loss"], loss_native=ld, loss_rel=abs(ld - fx["loss"]) / abs(fx["loss"]),
+    row = dict(test=f"full_{config}_dropout", scale=scale, loss_oracle=fx["loss"], loss_native=ld, loss_rel=abs(ld - fx["loss"]) / abs(fx["loss"]),
                grad_rel_sketch=sk_rel, worst_tensor_rel_sketch=worst_big, norm_outliers=len(bad_norm), sample_rel=c["rel"],
                sample_cos=c["cos"], sample_worst_cos=c["worst_cos"], fixture=True)
     _record(**row)
     print(row)
-    assert row["loss_rel"] < 2e-3, row                     # (a wrong or missing mask moves the loss by several 1e-2)
+    assert row["loss_rel"] < 1e-3, row                     # north_star's bar (a wrong or missing mask moves the loss by several 1e-2)
     assert row["grad_rel_sketch"] < 0.15 and row["worst_tensor_rel_sketch"] < 0.5, row
     assert not bad_norm, bad_norm[:5]
     assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row

@@ -1053,7 +1053,12 @@ DmaCfg heuristic_cfg(const T2VGemm& p);
 // tile rows of configuration `c` if its epilogue can emit T2VGemm.colsum for descriptor p, else 0
 int colsum_bm(const T2VGemm& p, const DmaCfg& c) {
   if (!w8_ok(p)) return 0;
-  if (c.tile >= W8_BASE) return t2v_gemm_w8_bm(c.tile - W8_BASE);
+  if (c.tile >= W8_BASE) {
+    const int w = c.tile - W8_BASE;
+    // (mode 2 multiplies COMPLETE accumulators: the staged epilogue of a K-group configuration sums the groups too late)
+    if (p.lr_mode == 2 && (w == 14 || w == 16 || w == 19 || w == 20 || c.split > 1)) return 0;
+    return t2v_gemm_w8_bm(w);
+  }
   static const int no_epi = [] { const char* e = getenv("T2V_GEMM_EPI"); return e && e[0] == '0'; }();
   if (no_epi || c.split > 1) return 0;
   switch (c.tile) {                       // the lean epilogue keeps a thread on one column chunk when BN/8 divides the threads
@@ -1073,8 +1078,10 @@ int launch_dma_cfg(const T2VGemm& p, const DmaCfg& c, hipStream_t s) {
                 "t2v_gemm: colsum requested but the kernel selected for this descriptor cannot emit it (ask t2v_gemm_colsum_rows first)");
   if (c.tile >= W8_BASE) {
     if (w8_ok(p)) return t2v_gemm_w8_launch(p, c.tile - W8_BASE, c.stages * 32, c.split, s);
+    T2V_CHECK_ARG(p.lr_mode == 0, "t2v_gemm: a rank-wide epilogue term (lr_mode) needs a descriptor the 8-wave kernels take");
     return launch_dma_cfg(p, heuristic_cfg(p), s);     // (a table entry met a descriptor outside the 8-wave domain)
   }
+  T2V_CHECK_ARG(p.lr_mode == 0, "t2v_gemm: a rank-wide epilogue term (lr_mode) is only built into the 8-wave kernels");
   T2VGemm q = p;
   int split = c.split;
   // the first 64 KB of the caller's scratch belong to the arrival counters of the 8-wave kernels' in-launch split-K (they must
@@ -1178,7 +1185,7 @@ int g_autotune = -1;
 TuneKey make_key(const T2VGemm& p) {
   TuneKey key;
   memset(&key, 0, sizeof(key));
-  key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = p.n_split > 0; key.out_mode = p.out_mode;
+  key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = (p.n_split > 0 ? 1 : 0) | (p.lr_mode << 1); key.out_mode = p.out_mode;
   key.has_res = p.R != nullptr; key.batch = p.batch > 1 ? p.batch : 1;
   if (p.a_mode == T2V_A_CONV) { key.KH = p.geom.KH; key.KW = p.geom.KW; key.sy = p.geom.sy; key.tdiv = p.geom.tdiv; key.up = p.geom.up; key.C = p.geom.C; }
   return key;
@@ -1190,34 +1197,144 @@ TuneKey make_key(const T2VGemm& p) {
 //   "live"          : unknown signatures are timed on first use (device synchronisation + HIP events; tuning runs only —
 //                     scripts/tune_gemm_table.py exports the result as the shipped table);
 //   "0"             : heuristic only.
+// Configuration of a launch with a rank-wide epilogue term (T2VGemm.lr_mode != 0): one of the KG = 1 8-wave tiles, column step
+// and K splits from a small cost model (rounds of 256 workgroups x tile area x (K per split + a fixed part)); table entries of
+// the same signature (lr_mode is part of the key) override it.
+bool lr_w8_cfg(int w) { return w == 12 || w == 14 || (w >= 16 && w <= 22 && w != 18); }   // (13 / 18: 256x256 LR kernels spill)
+int lr_w8_bn(int w) { return (w == 14 || w == 19) ? 192 : ((w == 16 || w == 20) ? 256 : 384); }
+
+DmaCfg lr_heuristic_cfg(const T2VGemm& p) {
+  const bool lr2 = p.lr_mode == 2;
+  // first choice: what the table holds for the SAME GEMM without the term — the rank-column launch [y | t] (forward) or the plain
+  // launch (backward-data) — when that is an 8-wave configuration with an LR instantiation
+  {
+    T2VGemm q = p;
+    q.lr_mode = 0;
+    if (lr2) {
+      q.N = p.N + p.lr_rp;
+      q.n_split = p.N;
+    }
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(make_key(q));
+    if (it != g_tuned.end() && it->second.tile >= W8_BASE && lr_w8_cfg(it->second.tile - W8_BASE)) {
+      DmaCfg c = it->second;
+      const int w = c.tile - W8_BASE, bn = lr_w8_bn(w);
+      int step = c.stages > 0 ? c.stages * 32 : bn;
+      if (lr2 && step > bn - 32) step = bn - 32;
+      c.stages = step / 32;
+      return c;
+    }
+  }
+  struct Cand { int cfg, bm, bn, kg; };
+  static const Cand cands[] = {{17, 128, 384, 1}, {19, 128, 192, 2}, {20, 128, 256, 2}};
+  const int nk = p.K / 64;
+  double best = 1e300;
+  DmaCfg out{W8_BASE + 17, 0, 1};
+  for (const Cand& c : cands) {
+    const int bn_eff = lr2 ? c.bn - 32 : c.bn;
+    int ntn = (p.N + bn_eff - 1) / bn_eff;
+    int step = ((p.N + ntn - 1) / ntn + 31) / 32 * 32;           // even split of N into whole fragments
+    if (step > bn_eff) step = bn_eff;
+    ntn = (p.N + step - 1) / step;
+    const long long tiles = (long long)((p.M + c.bm - 1) / c.bm) * ntn;
+    for (int sp : {1, 2, 3, 4, 6, 8}) {
+      if (sp > 1 && (nk / sp < 4 || !p.workspace ||
+                     65536ll + tiles * sp * c.bm * c.bn * 4 > (long long)p.workspace_bytes || tiles > 8000))
+        continue;
+      const long long rounds = (tiles * sp + 255) / 256;
+      const double cols = step + (lr2 ? 32 : 0);
+      const double cost = (double)rounds * c.bm * cols * ((double)p.K / sp + 1536.0 + (sp > 1 ? 768.0 : 0.0));
+      if (cost < best) {
+        best = cost;
+        out = DmaCfg{W8_BASE + c.cfg, step / 32, sp};
+      }
+    }
+  }
+  return out;
+}
+
 DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   if (g_autotune < 0) {
     const char* e = getenv("T2V_GEMM_AUTOTUNE");
     g_autotune = !e ? 1 : (e[0] == '0' ? 0 : ((e[0] == 'l' || e[0] == '2') ? 2 : 1));
   }
-  if (!g_autotune) return heuristic_cfg(p);
-  if (const char* f = getenv("T2V_GEMM_FORCE_CFG")) {       // "tile,stages,split": pin one configuration (counter passes, A/B runs)
-    int t = 0, st = 2, sp = 1;
-    if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && ((t >= 0 && t <= 9) || t >= W8_BASE)) return DmaCfg{t, st, sp < 1 ? 1 : sp};
+  const bool lr = p.lr_mode != 0;
+  if (g_autotune || lr) {
+    if (const char* f = getenv("T2V_GEMM_FORCE_CFG")) {     // "tile,stages,split": pin one configuration (counter passes, A/B runs)
+      int t = 0, st = 2, sp = 1;
+      if (sscanf(f, "%d,%d,%d", &t, &st, &sp) >= 1 && ((t >= 0 && t <= 9 && !lr) || t >= W8_BASE)) return DmaCfg{t, st, sp < 1 ? 1 : sp};
+    }
   }
+  if (lr) {
+    {
+      std::lock_guard<std::mutex> lk(g_tune_mu);
+      auto it = g_tuned.find(make_key(p));
+      if (it != g_tuned.end() && it->second.tile >= W8_BASE && lr_w8_cfg(it->second.tile - W8_BASE)) return it->second;
+    }
+    // (the choice never depends on whether column statistics are asked for: colsum_bm() answers 0 when the configuration this
+    //  returns cannot emit them — a mode-2 launch on K groups or K splits — and the caller then runs the statistics pass)
+    hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+    if (g_autotune != 2 || hipStreamIsCapturing(s, &cs0) != hipSuccess || cs0 != hipStreamCaptureStatusNone)
+      return lr_heuristic_cfg(p);
+  }
+  if (!lr && !g_autotune) return heuristic_cfg(p);
   const TuneKey key = make_key(p);
-  {
-    std::lock_guard<std::mutex> lk(g_tune_mu);
-    auto it = g_tuned.find(key);
-    if (it != g_tuned.end()) return it->second;
+  if (!lr) {
+    {
+      std::lock_guard<std::mutex> lk(g_tune_mu);
+      auto it = g_tuned.find(key);
+      if (it != g_tuned.end()) return it->second;
+    }
+    if (g_autotune != 2) return heuristic_cfg(p);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return heuristic_cfg(p);
   }
-  if (g_autotune != 2) return heuristic_cfg(p);
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return heuristic_cfg(p);
   // candidates
   std::vector<DmaCfg> cand;
+  if (lr) {
+    // launches with a rank-wide epilogue term: the LR instantiations of the 8-wave family x column steps x K splits
+    static const int W8LR[][3] = {{12, 128, 384}, {17, 128, 384}, {21, 128, 384}, {22, 128, 384}, {14, 128, 192}, {19, 128, 192},
+                                  {16, 128, 256}, {20, 128, 256}};
+    const bool lr2 = p.lr_mode == 2;
+    for (const auto& w : W8LR) {
+      const int bm = w[1], bn = w[2], bn_eff = lr2 ? bn - 32 : bn;
+      int steps[4], nsteps = 0;
+      auto add = [&](int st) {
+        if (st <= 0 || st > bn_eff) return;
+        for (int i = 0; i < nsteps; ++i)
+          if (steps[i] == st) return;
+        steps[nsteps++] = st;
+      };
+      add(bn_eff);
+      {
+        const int ntn = (p.N + bn_eff - 1) / bn_eff;
+        add(((p.N + ntn - 1) / ntn + 31) / 32 * 32);
+      }
+      if (p.N > 160) add(160);
+      if (p.N > 320) add(320);
+      for (int i = 0; i < nsteps; ++i) {
+        const int st = steps[i];
+        int ntn = 1;
+        if (lr2) ntn = (p.N + st - 1) / st;
+        else
+          while ((long long)(ntn - 1) * st + bn < p.N) ++ntn;
+        const long long wgs = (long long)((p.M + bm - 1) / bm) * ntn;
+        for (int sp : {1, 2, 3, 4, 6, 8}) {
+          if (sp > 1 && (wgs * sp > 320 || p.K / 64 / sp < 4 || !p.workspace)) continue;
+          if (wgs * sp < 40 && sp < 8 && p.K / 64 / (sp + 1) >= 4) continue;
+          cand.push_back(DmaCfg{W8_BASE + w[0], st / 32, sp});
+        }
+      }
+    }
+  }
   const bool can_split = p.workspace && p.batch <= 1 && p.out_mode == T2V_OUT_BF16;
   const int tiles_lo = p.N <= 32 ? 3 : 0, tiles_hi = p.N <= 32 ? 3 : 2;
   std::vector<int> tl;
-  for (int t = tiles_lo; t <= tiles_hi; ++t) tl.push_back(t);
+  if (!lr)
+    for (int t = tiles_lo; t <= tiles_hi; ++t) tl.push_back(t);
   static const int BMs[10] = {128, 128, 64, 128, 256, 128, 256, 256, 128, 128}, BNs[10] = {128, 64, 64, 32, 128, 320, 320, 256, 256, 384};
-  if (p.N > 64 && (long long)p.M * p.N >= (long long)256 * 128 * 128) tl.push_back(4);   // big outputs: 8-wave 256x128 tile
-  for (int t = 5; t <= 9; ++t) {
+  if (!lr && p.N > 64 && (long long)p.M * p.N >= (long long)256 * 128 * 128) tl.push_back(4);   // big outputs: 8-wave 256x128 tile
+  for (int t = 5; t <= 9 && !lr; ++t) {
     if (p.N < 256 || p.M < BMs[t]) continue;
     long long padded = (long long)((p.N + BNs[t] - 1) / BNs[t]) * BNs[t];
     if (padded * 100 > (long long)p.N * 115) continue;                     // <= 15 % padded columns
@@ -1239,7 +1356,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
       }
     }
   }
-  if (w8_ok(p) && !getenv("T2V_GEMM_NO_W8")) {
+  if (!lr && w8_ok(p) && !getenv("T2V_GEMM_NO_W8")) {
     // 8-wave one-workgroup-per-CU configurations (gemm_w8.hip): tile BM x BN of the production set, column steps that split N
     // evenly into whole fragments (or 160 / 320 = half / whole level-0 width), K splits that bring the launch to about one
     // round of workgroups
@@ -1283,7 +1400,7 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  DmaCfg best = heuristic_cfg(p);
+  DmaCfg best = lr ? lr_heuristic_cfg(p) : heuristic_cfg(p);
   float best_ms = 1e30f;
   (void)hipDeviceSynchronize();      // nothing else in flight (side-stream launches of earlier layers would skew the timings)
   // Time every candidate the way the step runs it: operands NOT resident in the XCD L2s (in the step they were just written
@@ -1328,6 +1445,7 @@ int dispatch(const T2VGemm& p, hipStream_t s) {
   if constexpr (DMA) {
     if (p.split_k <= 1 && !g_force_regstage) return launch_dma_cfg(p, pick_cfg(p, s), s);
   }
+  T2V_CHECK_ARG(p.lr_mode == 0, "t2v_gemm: a rank-wide epilogue term (lr_mode) needs the NN LDS-DMA path");
   const long long zdim = p.split_k > 1 ? p.split_k : (p.batch > 1 ? p.batch : 1);
   auto cost = [&](int bm, int bn, double eff) {
     long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zdim;
@@ -1430,6 +1548,13 @@ int check_gemm(const T2VGemm& p) {
   if (p.b_tapflip)
     T2V_CHECK_ARG(p.b_trans && !p.b_conv && p.a_mode == T2V_A_CONV && p.K == p.geom.KH * p.geom.KW * p.geom.C,
                   "t2v_gemm: b_tapflip needs b_trans=1 and a conv gather on A");
+  if (p.lr_mode != 0) {
+    T2V_CHECK_ARG(p.lr_mode == 1 || p.lr_mode == 2, "t2v_gemm: lr_mode must be 0, 1 or 2");
+    T2V_CHECK_ARG(!p.a_trans && !p.b_trans && p.batch <= 1 && p.split_k <= 1 && p.out_mode == T2V_OUT_BF16 && p.drop_p == 0.f && (p.N & 7) == 0,
+                  "t2v_gemm: a rank-wide epilogue term needs a plain NN launch with bf16 output");
+    T2V_CHECK_ARG(p.lr_b && ((uintptr_t)p.lr_b & 15) == 0 && (p.lr_mode == 2 || (p.lr_a && ((uintptr_t)p.lr_a & 15) == 0)),
+                  "t2v_gemm: lr_a / lr_b must be 16-byte aligned");
+  }
   return T2V_OK;
 }
 }  // namespace
@@ -1483,6 +1608,15 @@ extern "C" int t2v_gemm_w8(const T2VGemm* pp, int cfg, int nstep, int splits, t2
   if (int e = check_gemm(*pp)) return e;
   T2V_CHECK_ARG(w8_ok(*pp), "t2v_gemm_w8: descriptor outside the 8-wave kernels' domain (K%%64, C%%64, bf16 output, no dropout/batch)");
   return t2v_gemm_w8_launch(*pp, cfg, nstep, splits, (hipStream_t)stream);
+}
+
+extern "C" int t2v_gemm_lr_ok(const T2VGemm* pp) {
+  if (!pp || pp->lr_mode == 0) return 0;
+  T2VGemm p = *pp;
+  if (check_gemm(p) != T2V_OK || !w8_ok(p) || p.alpha != 1.f) return 0;
+  if (p.lr_rp < 8 || p.lr_rp > 32 || p.lr_rp % 8 != 0) return 0;
+  if (p.lr_mode == 2 && (p.N < 32 || p.n_split > 0)) return 0;
+  return 1;
 }
 
 extern "C" int t2v_gemm_colsum_rows(const T2VGemm* pp) {

@@ -75,7 +75,9 @@ struct EpiPlan {
 // CS: the instantiation with the LDS-staged epilogue (column statistics for the GroupNorm fusion need it); the other one
 // stores from registers.  Two kernels instead of a run-time branch: with both epilogues in one body the register allocator
 // spilled in each of them.
-template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS>
+// LR: the instantiation that knows the rank-wide epilogue term (T2VGemm.lr_*: the LoRA branch of a wrapped layer whose dropout
+// is active, folded into the launch) — separate kernels so that the plain ones keep their register allocation.
+template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS, bool LR = false>
 __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int nstep, const int ntn, const int splits, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(WM * WN * KG == 8 && (KG == 1 || KG == 2), "eight waves: WM x WN x KG");
@@ -136,7 +138,12 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   }
   const long long m0 = (long long)tm * BM;
   const int n0 = tn * nstep;
-  const int ncols = min(N - n0, tn == ntn - 1 ? BN : nstep);        // columns this tile owns (multiple of 8)
+  // lr_mode 2: the tile = nbase base columns, padded to whole fragments, + one fragment of rank columns (the lr_rp rows of B2:
+  // t = x (*) D^T is computed by EVERY column tile for its own epilogue)
+  const bool lr2 = LR && p.lr_mode == 2;
+  const int nbase = lr2 ? min(N - n0, nstep) : min(N - n0, tn == ntn - 1 ? BN : nstep);
+  const int rk0 = lr2 ? ((nbase + 31) & ~31) : 0x40000000;           // tile-local column of the rank fragment
+  const int ncols = lr2 ? rk0 + 32 : nbase;                          // columns this tile owns (multiple of 8)
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
 
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x80000000u, 0x00020000);
   __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x80000000u, 0x00020000);
   __amdgpu_buffer_rsrc_t srdB2 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.n_split > 0 ? p.B2 : p.B), 0, 0x80000000u, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)((p.n_split > 0 || (LR && p.lr_mode == 2)) ? p.B2 : p.B), 0, 0x80000000u, 0x00020000);
   if (is_conv) {
     conv_rows();
   } else {
@@ -207,10 +214,16 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     const int nl = tid / CPW + RPP * i;            // row of the tile's weight block
     const int n = n0 + nl;
     // a wave's WROWS rows of one pass start at a multiple of WROWS and n_split % WROWS == 0 (launch_w8): wave-uniform side
-    const bool second = p.n_split > 0 && (n0 + wave * WROWS + RPP * i) >= p.n_split;
+    bool second = p.n_split > 0 && (n0 + wave * WROWS + RPP * i) >= p.n_split;
+    unsigned row = (unsigned)(second ? n - p.n_split : n);
+    bool rok = nl < ncols;
+    if (lr2) {                                     // (rk0 and nbase are multiples of 8 = WROWS: wave-uniform side)
+      second = (wave * WROWS + RPP * i) >= rk0;
+      row = (unsigned)(second ? nl - rk0 : n);
+      rok = second ? (nl - rk0 < p.lr_rp) : (nl < nbase);
+    }
     if (second) b2lane |= 1u << i;
-    const unsigned row = (unsigned)(second ? n - p.n_split : n);
-    vb[i] = (nl < ncols) ? (row * (unsigned)(second ? p.ldb2 : p.ldb) + (unsigned)kc * 8u) * 2u : OOB;   // rows past the tile: zeros, no fetch
+    vb[i] = rok ? (row * (unsigned)(second ? p.ldb2 : p.ldb) + (unsigned)kc * 8u) * 2u : OOB;   // rows past the tile: zeros, no fetch
   }
 
   // pieces [lo, hi) of the LPT per-thread LDS-DMA loads of one stage (A passes first); the phased schedules spread a stage
@@ -543,7 +556,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   float* sC = (float*)smem;                        // PROWS x BN fp32, one 32-row fragment band per wave row and pass
   const int cc = tid % CPR, r0 = tid / CPR;
   const int col = n0 + cc * 8;
-  const bool cact = r0 < RPI && cc * 8 < ncols;
+  const bool cact = r0 < RPI && cc * 8 < nbase;
   const bool rankcol = p.n_split > 0 && col >= p.n_split;
   const float alpha = p.alpha, beta = p.beta;
   const bool act_silu = p.act == T2V_ACT_SILU;
@@ -586,6 +599,177 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   }
   const bool writer = role == 1;
 
+
+  // ---- rank-wide epilogue term (T2VGemm.lr_*, LR instantiations): acc[io][j] += lr_scale * mask * sum LA LB^T for the NB
+  // fragment bands this wave holds (band io = tile band ib0_ + io of its wave row).  Operands go straight into the MFMA that the
+  // K loop uses (weight side = first operand): LB fragment = 16 bytes of row `column` of lr_b, LA fragment = 16 bytes of a rank-
+  // wide row (mode 1: from memory, gathered per tap; mode 2: this tile's own rank-column accumulators, rounded to bf16 and
+  // passed between the wave columns through LDS — their register order IS a permuted k order, LB is read in the same order).
+  // One fragment's operands at a time (the compiler hoists the column fragments' loads of a tap into one batch: ~2 us per tap).
+  // Measured alternatives (scripts/lr_probe.py): both operands of two taps buffered in registers — spills, slower; both operands
+  // staged in LDS by all 512 threads — three barriers and index arithmetic cost more than the round trips they save.
+  auto rank_phase = [&](int ib0_, auto nb_tag) {
+    constexpr int NB = decltype(nb_tag)::value;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int rp = p.lr_rp, nk = rp > 16 ? 2 : 1, rkp = nk * 16;
+    const bool masked = p.lr_drop_p > 0.f;
+    const DropKey dkey = drop_key(masked ? eff_seed(p.lr_drop_seed, p.drop_epoch) : 0ull, p.lr_drop_p);
+    const float sc = masked ? p.lr_scale / (1.f - p.lr_drop_p) : p.lr_scale;
+    const bool direct = !masked && sc == 1.f;
+    const bf16_t* LB = (const bf16_t*)p.lr_b;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x4 zero4 = {0, 0, 0, 0};
+    bf16x8 la[NB][2];
+    unsigned rowg[NB];
+#pragma unroll
+    for (int io = 0; io < NB; ++io) rowg[io] = (unsigned)m0 + wr * TM + (ib0_ + io) * 32 + l31;
+    auto col0_of = [&](int j) { return wc * TN + j * 32; };
+    auto finish = [&](int io, int j, const f32x16& tmp) {       // acc += sc * mask * tmp
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t0 = sc * tmp[4 * q], t1 = sc * tmp[4 * q + 1], t2 = sc * tmp[4 * q + 2], t3 = sc * tmp[4 * q + 3];
+        if (masked) {
+          const unsigned long long idx = (unsigned long long)rowg[io] * (unsigned)N + (unsigned)(n0 + col0_of(j) + 8 * q + 4 * half);
+          const DropQuad h = drop_quad(dkey, idx >> 2);
+          t0 = (h.a & 0xffffu) >= dkey.thr ? t0 : 0.f;
+          t1 = (h.a >> 16) >= dkey.thr ? t1 : 0.f;
+          t2 = (h.b & 0xffffu) >= dkey.thr ? t2 : 0.f;
+          t3 = (h.b >> 16) >= dkey.thr ? t3 : 0.f;
+        }
+        acc[io][j][4 * q] += t0; acc[io][j][4 * q + 1] += t1; acc[io][j][4 * q + 2] += t2; acc[io][j][4 * q + 3] += t3;
+      }
+    };
+    if (lr2) {
+      // this tile's t = x (*) D^T sits in the accumulators of the rank fragment (wave column wc_r, fragment j_r): registers
+      // 8s .. 8s+7 of a lane = ranks 16s + {4h .. 4h+3, 8+4h .. 8+4h+3} of tile row (lane & 31) — used as k slots 0..7 as they are
+      bf16x8* xt = (bf16x8*)smem;                    // [WM * FM bands][2 k16 steps][64 lanes]
+      const int wc_r = rk0 / TN, j_r = (rk0 - wc_r * TN) >> 5;
+      if (KG == 2) __syncthreads();                  // (the K-group exchange's reads of this LDS are over)
+      if (wc == wc_r) {
+#pragma unroll
+        for (int jj = 0; jj < FN; ++jj) {
+          if (jj != j_r) continue;
+#pragma unroll
+          for (int io = 0; io < NB; ++io)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              if (ks >= nk) continue;
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = acc[io][jj][8 * ks + e];
+              const bf16x8 tv = pack8bf(v);
+              xt[((wr * FM + ib0_ + io) * 2 + ks) * 64 + lane] = tv;
+              if (tn == 0 && rowg[io] < (unsigned)M) {       // the saved down-projection of the backward pass
+                bf16_t* tp = (bf16_t*)p.D2 + rowg[io] * (unsigned)p.ldd2 + 16 * ks + 4 * half;
+                const bf16x4 lo = {tv[0], tv[1], tv[2], tv[3]}, hi = {tv[4], tv[5], tv[6], tv[7]};
+                if (16 * ks + 4 * half < rp) *(bf16x4*)tp = lo;
+                if (16 * ks + 8 + 4 * half < rp) *(bf16x4*)(tp + 8) = hi;
+              }
+            }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int io = 0; io < NB; ++io)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) la[io][ks] = ks < nk ? xt[((wr * FM + ib0_ + io) * 2 + ks) * 64 + lane] : zero8;
+      __syncthreads();                               // (the staging passes reuse this LDS)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if (col0_of(j) >= nbase) continue;           // rank fragment, padding
+        const bool cok = col0_of(j) + l31 < nbase;
+        const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + 4 * half;
+        bf16x8 lb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x4 lo = (cok && ks < nk) ? *(const bf16x4*)(lbp + 16 * ks) : zero4;
+          const bf16x4 hi = (cok && ks < nk) ? *(const bf16x4*)(lbp + 16 * ks + 8) : zero4;
+          lb[ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int io = 0; io < NB; ++io) {
+          f32x16 tmp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+          tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], tmp, 0, 0, 0);
+          if (nk > 1) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], tmp, 0, 0, 0);
+          finish(io, j, tmp);
+        }
+      }
+      return;
+    }
+    // ---- mode 1: LA from memory, natural k order (k slot = rank), one k16 step per 16 ranks and tap
+    const bf16_t* LA = (const bf16_t*)p.lr_a;
+    const int taps = p.lr_taps;
+    int gn[NB], gy[NB], gx[NB];
+    if (taps > 1) {
+      const int hw = g.Ho * g.Wo;
+#pragma unroll
+      for (int io = 0; io < NB; ++io) {
+        const int mm = rowg[io] < (unsigned)M ? (int)rowg[io] : 0;
+        gn[io] = mm / hw;
+        const int r = mm - gn[io] * hw;
+        gy[io] = r / g.Wo;
+        gx[io] = r - gy[io] * g.Wo;
+      }
+    }
+    auto load_la = [&](int tap) {
+      const int ky = taps > 1 ? tap / g.KW : 0, kx = taps > 1 ? tap - ky * g.KW : 0;
+#pragma unroll
+      for (int io = 0; io < NB; ++io) {
+        bool v = rowg[io] < (unsigned)M;
+        unsigned src = rowg[io];
+        if (taps > 1) {                              // stride-1 same-size window of the A gather (launch_w8 checks)
+          const int vy = gy[io] - g.py + ky, vx = gx[io] - g.px + kx;
+          v = v && (unsigned)vy < (unsigned)g.Hv && (unsigned)vx < (unsigned)g.Wv;
+          src = (unsigned)((gn[io] * g.Hv + vy) * g.Wv + vx);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          la[io][ks] = (v && ks < nk && 16 * ks + 8 * half < rp) ? *(const bf16x8*)(LA + src * (unsigned)p.lr_lda + 16 * ks + 8 * half) : zero8;
+      }
+    };
+    auto load_lb = [&](int j, int tap, bf16x8(&lb)[2]) {
+      const bool cok = col0_of(j) + l31 < nbase;
+      const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + tap * rkp + 8 * half;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) lb[ks] = (cok && ks < nk) ? *(const bf16x8*)(lbp + 16 * ks) : zero8;
+    };
+    if (direct) {                                    // no mask, unit scale: the products go straight into the accumulators
+      for (int tap = 0; tap < taps; ++tap) {
+        load_la(tap);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          if (col0_of(j) >= nbase) continue;
+          bf16x8 lb[2];
+          load_lb(j, tap, lb);
+#pragma unroll
+          for (int io = 0; io < NB; ++io) {
+            acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], acc[io][j], 0, 0, 0);
+            if (nk > 1) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], acc[io][j], 0, 0, 0);
+          }
+        }
+      }
+    } else {                                         // masked / scaled: one tap (launch_w8 checks), fragment by fragment
+      load_la(0);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if (col0_of(j) >= nbase) continue;
+        bf16x8 lb[2];
+        load_lb(j, 0, lb);
+#pragma unroll
+        for (int io = 0; io < NB; ++io) {
+          f32x16 tmp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+          tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], tmp, 0, 0, 0);
+          if (nk > 1) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], tmp, 0, 0, 0);
+          finish(io, j, tmp);
+        }
+      }
+    }
+  };
+
   // ---- register epilogue (every launch without column statistics): no staging through LDS.  The transposed accumulators give
   // a lane four consecutive columns per register quad; v_permlane32_swap between the quads q and q+1 of the two half-waves
   // leaves lane l < 32 with columns 8q .. 8q+7 and lane l + 32 with columns 8(q+1) .. 8(q+1)+7 of tile row (l & 31): the same
@@ -614,7 +798,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       auto chunk_pos = [&](int io, int j, int qp, unsigned& row, int& ccol, bool& ok, bool& rk) {
         row = (unsigned)m0 + wr * TM + (ib0 + io) * 32 + (lane & 31);
         ccol = n0 + wc * TN + j * 32 + 8 * (qp + half);
-        ok = row < (unsigned)M && (ccol - n0) < ncols;
+        ok = row < (unsigned)M && (ccol - n0) < nbase;
         rk = p.n_split > 0 && ccol >= p.n_split;
       };
       auto prefetch = [&](int ch, Pre& pf) {
@@ -632,7 +816,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
       };
       Pre cur, nxt;
-      if (KG == 2 && role == 0) prefetch(0, cur);      // (in flight under the K-group exchange)
+      if (KG == 2 && role == 0 && !LR) prefetch(0, cur);      // (in flight under the K-group exchange)
       if constexpr (KG == 2) {
         constexpr int PER = OWN * FN * 4 * 64;        // float4 slots per (receiving group, wave pair)
         float4* X = (float4*)smem;
@@ -720,7 +904,11 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
       }
       if (!writer) {
-        if (KG == 1 || role != 0) prefetch(0, cur);    // (the slab reduction needs the registers)
+        if constexpr (LR) {
+          // (after the K-group exchange and the split-K reduction: the accumulators are complete — mode 2 multiplies them)
+          if (p.lr_mode != 0) rank_phase(ib0, std::integral_constant<int, OWN>{});
+        }
+        if (KG == 1 || role != 0 || LR) prefetch(0, cur);    // (the slab reduction / the rank phase need the registers)
 #pragma unroll
         for (int ch = 0; ch < 2 * OWN * FN; ++ch) {      // chunk = (fragment, quad pair)
           const int io = (ch >> 1) / FN, j = (ch >> 1) % FN, qp = 2 * (ch & 1);
@@ -795,6 +983,11 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   }
   // ---- column statistics of the stored tile (T2VGemm.colsum, GroupNorm fusion): every thread accumulates its 8 columns over
   // the rows it writes; the RPI threads of a column chunk are combined in fixed order through LDS after the last pass
+  if constexpr (LR) {
+    // staged path: the term is added to ONE of the partial sums that meet later (K group 0 of split 0); mode 2 needs complete
+    // accumulators and therefore KG == 1 and a single split (launch_w8)
+    if (p.lr_mode != 0 && (KG == 1 || kg == 0) && bz == 0) rank_phase(0, std::integral_constant<int, FM>{});
+  }
   CsState cst;
   cs_init(cst, p, cs_mode, cact && !rankcol, m0, col, Nb);
   const bf16_t* CX = (cs_mode == 2 && cact && !rankcol) ? (const bf16_t*)p.cs_x : nullptr;
@@ -938,7 +1131,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   }
   if (cs_mode != 0 && role != 1) {
     __syncthreads();                                 // staging buffer free: [RPI][BN][2] partials of the column chunks
-    cs_flush(cst, p, (float*)smem, cact && !rankcol, r0, RPI, cc, BN, tid, NT, n0, ncols, Nb, tm, BM);
+    cs_flush(cst, p, (float*)smem, cact && !rankcol, r0, RPI, cc, BN, tid, NT, n0, nbase, Nb, tm, BM);
   }
   }
   if (dbg & 8) tl[7] = __builtin_readcyclecounter();
@@ -959,7 +1152,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS>
+template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS, bool LR = false>
 int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BKT * 2;
   constexpr int EPI = EpiPlan<BN, WM, BM / WM / 32>::BYTES;
@@ -970,7 +1163,35 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
                 "t2v_gemm_w8: colsum mode 2 needs x / sums / gamma / beta, no residual, and tiles inside a domain");
   T2V_CHECK_ARG(p.n_split <= 0 || p.n_split % (64 / (BKT / 8)) == 0,
                 "t2v_gemm_w8: n_split=%d must be a multiple of %d for this configuration", p.n_split, 64 / (BKT / 8));
-  auto kern = gemm_w8_kernel<BM, BN, WM, WN, KG, NSTAGE, SCHED, BKT, CS>;
+  const bool lr2 = LR && p.lr_mode == 2;
+  if constexpr (LR) {
+    T2V_CHECK_ARG(p.lr_mode == 1 || p.lr_mode == 2, "t2v_gemm_w8: lr_mode %d", p.lr_mode);
+    T2V_CHECK_ARG(p.lr_rp >= 8 && p.lr_rp <= 32 && p.lr_rp % 8 == 0 && p.lr_b && p.lr_ldb % 8 == 0 && p.alpha == 1.f,
+                  "t2v_gemm_w8: rank-wide epilogue term needs a padded rank of 8..32, lr_b and alpha == 1");
+    T2V_CHECK_ARG(p.lr_drop_p >= 0.f && p.lr_drop_p < 1.f, "t2v_gemm_w8: lr_drop_p must be in [0, 1)");
+    T2V_CHECK_ARG((long long)p.N * p.lr_ldb < 0x7ff00000ll, "t2v_gemm_w8: lr_b too large for 32-bit offsets");
+    if (p.lr_mode == 1) {
+      T2V_CHECK_ARG(p.lr_a && p.lr_lda % 8 == 0 && p.lr_lda >= p.lr_rp && p.lr_taps >= 1, "t2v_gemm_w8: lr_mode 1 needs lr_a [rows, lr_lda >= lr_rp]");
+      T2V_CHECK_ARG((long long)p.M * p.lr_lda < 0x7ff00000ll, "t2v_gemm_w8: lr_a too large for 32-bit offsets");
+      if (p.lr_taps > 1) {
+        const T2VConvGeom& g = p.geom;
+        T2V_CHECK_ARG(p.a_mode == T2V_A_CONV && p.lr_taps == g.KH * g.KW && g.sy == 1 && g.sx == 1 && g.tdiv == 1 && g.up == 0 &&
+                          g.Hv == g.Ho && g.Wv == g.Wo,
+                      "t2v_gemm_w8: a windowed rank-wide term follows the A gather's own stride-1 same-size window");
+        T2V_CHECK_ARG(p.lr_drop_p == 0.f && p.lr_scale == 1.f, "t2v_gemm_w8: a windowed rank-wide term takes no mask / scale (fold the scale into lr_b)");
+      }
+    } else {
+      T2V_CHECK_ARG(KG == 1 || !CS, "t2v_gemm_w8: lr_mode 2 with column statistics needs a configuration without K groups");
+      T2V_CHECK_ARG(p.n_split <= 0 && p.B2 && p.D2 && p.ldb2 % 8 == 0 && p.ldd2 % 8 == 0 && p.ldd2 >= p.lr_rp && p.lr_taps <= 1 && p.b2_klen <= 0,
+                    "t2v_gemm_w8: lr_mode 2 takes the down factor in B2 / D2 with n_split = 0");
+      T2V_CHECK_ARG((long long)p.lr_rp * p.ldb2 * 2 < 0x7ff00000ll && (long long)p.M * p.ldd2 < 0x7ff00000ll, "t2v_gemm_w8: lr_mode 2 offsets");
+      if (CS) splits = 1;                          // the staged epilogue reduces the splits after the rank phase (t2v_gemm never
+                                                   // pairs the two: colsum_bm() answers 0 for a split configuration)
+    }
+  } else {
+    T2V_CHECK_ARG(p.lr_mode == 0, "t2v_gemm_w8: this configuration has no rank-wide epilogue term (lr_mode %d)", p.lr_mode);
+  }
+  auto kern = gemm_w8_kernel<BM, BN, WM, WN, KG, NSTAGE, SCHED, BKT, CS, LR>;
   static bool attr_set = false;
   if (!attr_set) {
     if (SMEM > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -981,7 +1202,12 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   if (nstep <= 0) nstep = BN;
   const int ntm = (p.M + BM - 1) / BM;
   int ntn = 1;
-  while ((long long)(ntn - 1) * nstep + BN < p.N) ++ntn;      // the last tile takes up to BN columns
+  if (lr2) {                                       // every tile: up to nstep base columns + one fragment of rank columns
+    if (nstep > BN - 32) nstep = BN - 32;
+    ntn = (p.N + nstep - 1) / nstep;
+  } else {
+    while ((long long)(ntn - 1) * nstep + BN < p.N) ++ntn;      // the last tile takes up to BN columns
+  }
   // K splits: every split gets at least NSTAGE stages; the slabs + counters must fit the caller's scratch (first 64 KB =
   // counters, zero when the scratch is first handed over; the kernels leave them zero)
   const int nt_all = p.K / BKT;
@@ -1016,6 +1242,23 @@ int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStre
   // the staged-epilogue kernels serve the launches that ask for column statistics (and T2V_W8_STAGED=1: A/B runs, tests)
   static const bool force_staged = [] { const char* e = getenv("T2V_W8_STAGED"); return e && atoi(e) != 0; }();
   const bool staged = p.colsum != nullptr || force_staged;
+  if (p.lr_mode != 0) {                            // rank-wide epilogue term: the KG = 1 members of the production set
+    switch (cfg) {
+      case 12: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 4, 64, false, true>(p, nstep, splits, s);
+      case 13: return staged ? launch_w8<256, 256, 4, 2, 1, 2, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<256, 256, 4, 2, 1, 2, 4, 64, false, true>(p, nstep, splits, s);
+      case 17: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 5, 64, false, true>(p, nstep, splits, s);
+      case 18: return staged ? launch_w8<256, 256, 4, 2, 1, 2, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<256, 256, 4, 2, 1, 2, 5, 64, false, true>(p, nstep, splits, s);
+      case 21: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 4, 64, false, true>(p, nstep, splits, s);
+      case 22: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 5, 64, false, true>(p, nstep, splits, s);
+      // K groups: the register epilogue runs the rank phase after the groups have met (mode 2 too); the staged one adds a
+      // mode-1 term to group 0's partial sums
+      case 14: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 4, 64, false, true>(p, nstep, splits, s);
+      case 16: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 4, 64, false, true>(p, nstep, splits, s);
+      case 19: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 5, 64, false, true>(p, nstep, splits, s);
+      case 20: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 5, 64, false, true>(p, nstep, splits, s);
+      default: t2v_set_error("t2v_gemm_w8: configuration %d has no rank-wide epilogue term (12-14, 16-22 do)", cfg); return T2V_EINVAL;
+    }
+  }
   switch (cfg) {
     //                       BM   BN  WM WN KG NS SCHED BK
     case 0: return launch_w8<128, 384, 2, 2, 2, 2, 0, 64, true>(p, nstep, splits, s);      // wave 64x192, K groups, classic ring

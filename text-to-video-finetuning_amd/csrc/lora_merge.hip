@@ -86,6 +86,46 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const T2VLoraMergeJob* 
   }
 }
 
+
+// ---- transposed bf16 copies of the factors for the rank-wide epilogue term of the GEMM kernels (T2VGemm.lr_b): with the
+// wrappers' dropout active the branch cannot be merged into W; the base layer's launch then adds s mask (t U^T) (forward) and
+// s dt (*) D^T (backward-data) itself and wants the factor ROW-per-output-column, ranks contiguous:
+//   upT[n, j]            = U[j, n]                                   [Np, rk]          (rk = 16 or 32: ranks padded with zeros)
+//   dnT[c, tap*rk + j]   = scale * D[j, (taps-1-tap)*Cp + c]         [Cp, taps*rk]     (flipped taps: the backward-data window)
+// One launch for all layers: chunk (8 ranks of one row) -> job by binary search over the jobs' first chunks.
+__global__ __launch_bounds__(256) void lora_prep_kernel(const T2VLoraPrepJob* __restrict__ jobs, int njobs, long long total) {
+  const long long ch = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (ch >= total) return;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].chunk0 <= ch) lo = mid;
+    else hi = mid - 1;
+  }
+  const T2VLoraPrepJob J = jobs[lo];
+  long long r = ch - J.chunk0;
+  const int cpr_u = J.rk / 8;
+  const long long nu = (long long)J.Np * cpr_u;
+  bf16x8 o;
+  if (r < nu) {                                    // up: row n, ranks j0 .. j0+7
+    const int j0 = (int)(r / J.Np) * 8, n = (int)(r % J.Np);             // (consecutive threads: consecutive n — coalesced reads)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (j0 + e < J.rp) ? (short)f2bf(J.up[(long long)(j0 + e) * J.ldu + n]) : (short)0;
+    *(bf16x8*)((bf16_t*)J.upT + (long long)n * J.rk + j0) = o;
+    return;
+  }
+  r -= nu;
+  const long long per_tap = (long long)J.Cp * cpr_u;
+  const int tap = (int)(r / per_tap);
+  r -= (long long)tap * per_tap;
+  const int j0 = (int)(r / J.Cp) * 8, c = (int)(r % J.Cp);
+  const long long K = (long long)J.taps * J.Cp;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    o[e] = (j0 + e < J.rp) ? (short)f2bf(J.scale * J.down[(long long)(j0 + e) * K + (long long)(J.taps - 1 - tap) * J.Cp + c]) : (short)0;
+  *(bf16x8*)((bf16_t*)J.dnT + (long long)c * ((long long)J.taps * J.rk) + (long long)tap * J.rk + j0) = o;
+}
+
 }  // namespace
 
 // Host-side planning: validates the jobs, assigns each its first tile (`tile0`) and fills the tile -> job map.
@@ -119,6 +159,16 @@ extern "C" int t2v_lora_merge(const T2VLoraMergeJob* jobs_dev, int njobs, const 
                               t2v_stream_t stream) {
   T2V_CHECK_ARG(jobs_dev && tile_job_dev && njobs > 0 && ntiles > 0 && ntiles < (1ll << 31), "t2v_lora_merge: bad arguments");
   hipLaunchKernelGGL(lora_merge_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, jobs_dev, tile_job_dev);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+// chunks of one prep job (host side: the caller accumulates them into T2VLoraPrepJob.chunk0 and the launch's total)
+extern "C" long long t2v_lora_prep_chunks(int Np, int Cp, int taps, int rk) { return ((long long)Np + (long long)Cp * taps) * (rk / 8); }
+
+extern "C" int t2v_lora_prep(const T2VLoraPrepJob* jobs_dev, int njobs, long long total_chunks, t2v_stream_t stream) {
+  T2V_CHECK_ARG(jobs_dev && njobs > 0 && total_chunks > 0 && (total_chunks + 255) / 256 < (1ll << 31), "t2v_lora_prep: bad arguments");
+  hipLaunchKernelGGL(lora_prep_kernel, dim3((unsigned)((total_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs, total_chunks);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

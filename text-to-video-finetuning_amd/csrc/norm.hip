@@ -519,24 +519,6 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(const float* __r
   }
 }
 
-// library-owned scratch for the per-workgroup parameter-gradient partials (one buffer per device, grown outside captures)
-float* param_grad_scratch(long long floats) {
-  static float* buf[16] = {nullptr};
-  static long long cap[16] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (cap[dev] < floats) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    float* nb = nullptr;
-    const long long want = floats < (8ll << 20) ? (8ll << 20) : floats;     // 32 MB to begin with
-    if (hipMalloc((void**)&nb, (size_t)want * 4) != hipSuccess) return nullptr;
-    (void)st;
-    buf[dev] = nb;                                       // (the old buffer may still be read by queued kernels: it is leaked,
-    cap[dev] = want;                                     //  at most once or twice per process)
-  }
-  return buf[dev];
-}
-
 // ------------------------------------------------------------------ GroupNorm statistics from GEMM-epilogue column sums
 // grid (G, ndomains), 256 threads: thread i owns items i, i+256, .. of the (tile, column-of-group) list — a fixed assignment
 // with the loads of up to 8 items in flight — and the partials are added in a fixed two-level order: bit-reproducible.
@@ -654,10 +636,20 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
   return T2V_OK;
 }
 
+static int ln_bwd_grid(int rows, int C, bool with_pg) {
+  const int rw = C <= 512 ? 8 : (C <= 1024 ? 4 : 2);
+  return min((rows + 4 * rw - 1) / (4 * rw), with_pg ? 2048 : 16384);
+}
+// sizes of the caller-owned scratch for the per-workgroup parameter-gradient partial rows (Face 2: the library owns no memory)
+extern "C" long long t2v_gn_bwd_pg_floats(int ndomains, int rows_per_domain, int C) {
+  return (long long)gn_splits(ndomains, rows_per_domain, C) * ndomains * 2 * C;
+}
+extern "C" long long t2v_layernorm_bwd_pg_floats(int rows, int C) { return (long long)ln_bwd_grid(rows, C, true) * 2 * C; }
+
 extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, long long lddy, int ndomains,
                                 int rows_per_domain, int C, int G, const float* sums, const float* gamma, const float* beta,
                                 float eps, int silu, float drop_p, unsigned long long drop_seed, float* bsums, float* workspace,
-                                float* dgamma, float* dbeta, t2v_stream_t stream) {
+                                float* dgamma, float* dbeta, float* pg_workspace, t2v_stream_t stream) {
   if (int e = gn_check("t2v_gn_bwd_stats", C, G, ldx)) return e;
   T2V_CHECK_ARG(x && dy && sums && gamma && beta && bsums && workspace && lddy % 8 == 0 && G <= 128, "t2v_gn_bwd_stats: bad args");
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_gn_bwd_stats: dgamma/dbeta must both be set or NULL");
@@ -668,8 +660,8 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
   float* pg = nullptr;
   const int nwg = ns * ndomains;
   if (dgamma) {
-    pg = param_grad_scratch((long long)nwg * 2 * C);
-    T2V_CHECK_ARG(pg, "t2v_gn_bwd_stats: cannot allocate the parameter-gradient scratch (%lld floats)", (long long)nwg * 2 * C);
+    pg = pg_workspace;
+    T2V_CHECK_ARG(pg, "t2v_gn_bwd_stats: dgamma / dbeta need pg_workspace (t2v_gn_bwd_pg_floats() = %lld floats)", (long long)nwg * 2 * C);
   }
   if (dgamma)
     T2V_LAUNCH_FIRST(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
@@ -722,18 +714,17 @@ extern "C" int t2v_layernorm_fwd(const void* x, long long ldx, void* y, long lon
 
 extern "C" int t2v_layernorm_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
                                  int rows, int C, const float* gamma, const float* stats, float* dgamma, float* dbeta,
-                                 const void* addend, long long ldadd, t2v_stream_t stream) {
+                                 float* pg_workspace, const void* addend, long long ldadd, t2v_stream_t stream) {
   T2V_CHECK_ARG(!addend || ldadd % 8 == 0, "t2v_layernorm_bwd: addend leading dimension must be a multiple of 8");
   T2V_CHECK_ARG(x && dy && dx && gamma && stats && rows > 0, "t2v_layernorm_bwd: bad args");
   T2V_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
                 "t2v_layernorm_bwd: need C%%8==0, C<=2048 (C=%d)", C);
   T2V_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "t2v_layernorm_bwd: dgamma/dbeta must both be set or NULL");
-  const int rw = C <= 512 ? 8 : (C <= 1024 ? 4 : 2);
-  const int grid = min((rows + 4 * rw - 1) / (4 * rw), dgamma ? 2048 : 16384);
+  const int grid = ln_bwd_grid(rows, C, dgamma != nullptr);
   float* pg = nullptr;
   if (dgamma) {
-    pg = param_grad_scratch((long long)grid * 2 * C);
-    T2V_CHECK_ARG(pg, "t2v_layernorm_bwd: cannot allocate the parameter-gradient scratch (%lld floats)", (long long)grid * 2 * C);
+    pg = pg_workspace;
+    T2V_CHECK_ARG(pg, "t2v_layernorm_bwd: dgamma / dbeta need pg_workspace (t2v_layernorm_bwd_pg_floats() = %lld floats)", (long long)grid * 2 * C);
   }
   auto go = [&](auto kern, auto kern_pg) {
     if (dgamma)

@@ -197,6 +197,11 @@ _gn_last = [None]        # forward record of the GroupNorm evaluated last (attac
 _bwd_cs = {}             # data_ptr of a backward-data result -> (buffer, tile rows, M, C): consumed by the GroupNorm backward
 
 
+def _lr_ok(kw):
+    """True if the library runs this descriptor with its rank-wide epilogue term (T2VGemm.lr_*: 8-wave kernels only)."""
+    return bool(nv.lib().t2v_gemm_lr_ok(C.byref(make_gemm(**kw))))
+
+
 def launch_gemm_pair(kw_a, kw_b):
     nv.call("t2v_gemm_pair", C.byref(make_gemm(**kw_a)), C.byref(make_gemm(**kw_b)), nv.stream())
 
@@ -204,7 +209,7 @@ def launch_gemm_pair(kw_a, kw_b):
 def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0, b_conv=0, geom=None, out_mode=0,
                 bias=None, rowbias=None, ldrb=0, rows_per_rb=0, R=None, ldr=0, alpha=1.0, beta=1.0, act=0, batch=1,
                 strideA=0, strideB=0, strideD=0, strideR=0, split_k=1, drop_p=0.0, drop_seed=0, B2=None, ldb2=0, n_split=0,
-                D2=None, ldd2=0, b_tapflip=0, b2_k0=0, b2_klen=0, use_ws=True):
+                D2=None, ldd2=0, b_tapflip=0, b2_k0=0, b2_klen=0, use_ws=True, lr=None):
     g = Gemm = nv.Gemm()
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.a_mode, g.a_trans = A, lda, a_mode, a_trans
@@ -221,6 +226,11 @@ def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0
     g.drop_p, g.drop_seed = drop_p, drop_seed
     g.B2, g.ldb2, g.n_split, g.D2, g.ldd2, g.b_tapflip = B2, ldb2, n_split, D2, ldd2, b_tapflip
     g.b2_k0, g.b2_klen = b2_k0, b2_klen
+    if lr is not None:      # rank-wide epilogue term (T2VGemm.lr_*): the LoRA branch of a dropped wrapper inside the base launch
+        g.lr_mode, g.lr_rp, g.lr_taps = lr["mode"], lr["rp"], lr.get("taps", 1)
+        g.lr_a, g.lr_lda = lr.get("a"), lr.get("lda", 0)
+        g.lr_b, g.lr_ldb = lr["b"], lr["ldb"]
+        g.lr_scale, g.lr_drop_p, g.lr_drop_seed = lr.get("scale", 1.0), lr.get("drop_p", 0.0), lr.get("drop_seed", 0)
     if use_ws and out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
         ws = _gemm_workspace()          # one scratch per device: main-stream launches only (stream order serialises its users)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -356,10 +366,21 @@ def launch_gemm_dropmask(dy, out, drop_p, drop_seed):
             drop_seed, nv.stream())
 
 
+def _take_gn(x):
+    """The forward record of the GroupNorm that produced `x`, for a layer that consumes x — and one more registered consumer.
+    Only a norm output with exactly ONE consumer may get its backward sums from that consumer's backward-data launch: with
+    several (the VAE attention feeds to_q / to_k / to_v) autograd adds their gradients in place into the first one's buffer, and
+    sums taken from that one launch would describe a partial gradient."""
+    rec = getattr(x, "_t2v_gn", None)
+    if rec is not None:
+        rec["uses"] = rec.get("uses", 0) + 1
+    return rec
+
+
 def _gn_bwd_request(gn, M, C_):
     """Column-statistics request for a backward-data launch whose result is the gradient of a GroupNorm output `gn` recorded:
     the two sums of t2v_gn_bwd_stats ride in the epilogue (mode 2).  None when the record does not fit this launch."""
-    if gn is None or gn["drop_p"] > 0.0 or gn["x"].shape != (M, C_) or gn["want_pg"]:
+    if gn is None or gn.get("uses", 1) != 1 or gn["drop_p"] > 0.0 or gn["x"].shape != (M, C_) or gn["want_pg"]:
         return None
     return {"mode": 2, "x": gn["x"].data_ptr(), "ldx": _ld(gn["x"]), "sums": gn["sums"].data_ptr(), "gamma": gn["g32"].data_ptr(),
             "beta": gn["b32"].data_ptr(), "eps": gn["eps"], "G": gn["G"], "silu": gn["silu"], "domain_rows": gn["rpd"]}
@@ -368,6 +389,7 @@ def _gn_bwd_request(gn, M, C_):
 def _note_bwd_cs(dx, info):
     if info is not None:
         _bwd_cs[dx.data_ptr()] = info
+        _join_at_end_of_backward()           # entries nobody consumed must not outlive the pass (a later tensor could land on the address)
 
 
 class _Dropout(torch.autograd.Function):
@@ -525,6 +547,7 @@ def flush_wgrads():
 
 def _end_of_backward():
     _side["cb"] = False
+    _bwd_cs.clear()
     join_side_stream()
     _wq["per_pass"] = max(_wq.get("per_pass", 0), _wq.get("seen", 0))
     _wq["seen"] = 0
@@ -578,8 +601,10 @@ class _LoraLayer(torch.autograd.Function):
     With dropout off, g = dy and dt rides in the backward-data launch as rank columns."""
 
     @staticmethod
-    def forward(ctx, x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, e, scale, drop_p=0.0, drop_seed=0):
+    def forward(ctx, x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, e, scale, drop_p=0.0, drop_seed=0, colsum=False,
+                gn=None):
         x = _mat(x, "x")
+        ctx.gn = gn
         wq = prepared_weight(w_base, "fwd")
         npad, K = wq.shape
         cin_p = K // cfg.taps()
@@ -596,12 +621,30 @@ class _LoraLayer(torch.autograd.Function):
         if residual is not None:
             residual = _mat(residual, "residual")
         conv = cfg.kind != "linear"
-        launch_gemm(M=M, N=npad + e.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=npad,
-                    a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(cin_p) if conv else None, bias=nv.ptr(b32),
-                    rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
-                    R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
-                    B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
-        _lowrank_update(y, t, e.up_w16, M, npad, e.rp, scale, drop_p, drop_seed)     # y += s mask (t U^T)
+        # Epilogue form (round 4): every column tile of the base launch carries the rank rows of D, multiplies its own
+        # t = x (*) D^T with U in the epilogue and adds s mask (t U^T) before the store — no pass over y, and the GroupNorm
+        # statistics of the FINAL y can ride along.  Needs the step's transposed factor copies (lora_bank.PrepPlan) and a
+        # descriptor the 8-wave kernels take.
+        ctx.prep_ok = _lora_epi and getattr(e, "prep_scale", None) == scale and e.rp <= 32
+        kw = None
+        if ctx.prep_ok and M >= _LORA_EPI_MIN_ROWS:
+            kw = dict(M=M, N=npad, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=npad,
+                      a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(cin_p) if conv else None,
+                      bias=nv.ptr(b32), rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0,
+                      rows_per_rb=rpr, R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
+                      B2=e.down_w16.data_ptr(), ldb2=K, D2=t.data_ptr(), ldd2=e.rp,
+                      lr=dict(mode=2, rp=e.rp, b=e.up_t16.data_ptr(), ldb=e.rk, scale=scale, drop_p=drop_p, drop_seed=drop_seed))
+            if not _lr_ok(kw):
+                kw = None
+        if kw is not None:
+            _cs_last[0] = launch_gemm(cs={"mode": 1} if colsum else None, **kw)
+        else:
+            launch_gemm(M=M, N=npad + e.rp, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=npad,
+                        a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(cin_p) if conv else None, bias=nv.ptr(b32),
+                        rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0, rows_per_rb=rpr,
+                        R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
+                        B2=e.down_w16.data_ptr(), ldb2=K, n_split=npad, D2=t.data_ptr(), ldd2=e.rp)
+            _lowrank_update(y, t, e.up_w16, M, npad, e.rp, scale, drop_p, drop_seed)     # y += s mask (t U^T)
         ctx.cfg, ctx.e, ctx.scale, ctx.drop = cfg, e, scale, (drop_p, drop_seed)
         ctx.has = (rowbias is not None, residual is not None)
         ctx.save_for_backward(x, t, w_base, rowbias)
@@ -641,7 +684,22 @@ class _LoraLayer(torch.autograd.Function):
             launch_gemm(M=M, N=e.rp, K=npad, A=g.data_ptr(), lda=_ld(g), B=e.up_w16.data_ptr(), ldb=_ld(e.up_w16),
                         D=dt.data_ptr(), ldd=e.rp)
         b2 = dict(B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), n_split=cin_p, D2=dt.data_ptr(), ldd2=e.rp) if ride else {}
-        if need_dx and not conv:
+        # Epilogue form: dx = dy (*) W^T + s dt (*) D^T in ONE launch — the rank-wide term is a few extra MFMAs per output
+        # fragment on operands read straight from memory (dt, the flipped-tap transpose of s D), no pass over dx
+        kw = None
+        if (need_dx and not ride and ctx.prep_ok and x.shape[0] == M and
+                (not conv or (_wgrad_window_ok(cfg.fwd_geom(cin_p), M) and cfg.taps() in (1, 3, 9)))):
+            wb = prepared_weight(w_base, "bwd")
+            dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+            kw = dict(M=M, N=cin_p, K=wb.shape[1], A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1], D=dx.data_ptr(),
+                      ldd=cin_p, a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.bwd_geom(npad) if conv else None,
+                      lr=dict(mode=1, rp=e.rp, taps=cfg.taps(), a=dt.data_ptr(), lda=e.rp, b=e.down_t16.data_ptr(),
+                              ldb=cfg.taps() * e.rk))
+            if not _lr_ok(kw):
+                kw, dx = None, None
+        if kw is not None:
+            _note_bwd_cs(dx, launch_gemm(cs=_gn_bwd_request(ctx.gn, M, cin_p), **kw))
+        elif need_dx and not conv:
             # linear: [dx | dt] = dy [W^T | U] in ONE launch (dt rides as rp extra output columns)
             wb = prepared_weight(w_base, "bwd")
             dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
@@ -684,10 +742,12 @@ class _LoraLayer(torch.autograd.Function):
         # factor gradients dU = s t^T g, dD = s dt^T x, accumulated in the flat fp32 gradient buffer (side stream)
         _lora_side_grads(x, g.data_ptr(), _ld(g), [g, dy, x, t, dt], cfg, e, scale, M, npad, cin_p, t=t, dt=dt,
                          drop=(drop_p, drop_seed) if fused_mask else None)
-        return dx, None, None, None, None, drb, dres, None, None, None, None, None
+        return dx, None, None, None, None, drb, dres, None, None, None, None, None, None, None
 
 
 _drop_fuse = os.environ.get("T2V_DROP_FUSE", "1") != "0"       # A/B switch: masks regenerated inside the backward kernels
+_lora_epi = os.environ.get("T2V_LORA_EPI", "1") != "0"         # A/B switch: the dropped LoRA branch as an epilogue term of the base launch
+_LORA_EPI_MIN_ROWS = int(os.environ.get("T2V_LORA_EPI_MIN_ROWS", "128"))
 
 
 def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=None, dt=None, drop=None):
@@ -827,7 +887,7 @@ class _LoraMerged(torch.autograd.Function):
 def lora_merged(x, bias, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None, colsum=False):
     _cs_last[0] = None
     return _attach_cs(_LoraMerged.apply(x, down_w, up_w, bias, rowbias, residual, cfg, entry, float(scale), bool(colsum),
-                                        getattr(x, "_t2v_gn", None)))
+                                        _take_gn(x)))
 
 
 class _LoraGroupMerged(torch.autograd.Function):
@@ -1016,9 +1076,11 @@ def _wgrad_window_ok(g, rows):
             and g.KH * g.KW in (1, 3, 9) and rows % (g.Hv * g.Wv) == 0)
 
 
-def lora_layer(x, w_base, b_base, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None, drop_p=0.0, drop_seed=0):
-    return _LoraLayer.apply(x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, entry, float(scale), float(drop_p),
-                            int(drop_seed))
+def lora_layer(x, w_base, b_base, down_w, up_w, cfg, entry, scale, rowbias=None, residual=None, drop_p=0.0, drop_seed=0,
+               colsum=False):
+    _cs_last[0] = None
+    return _attach_cs(_LoraLayer.apply(x, w_base, b_base, down_w, up_w, rowbias, residual, cfg, entry, float(scale), float(drop_p),
+                                       int(drop_seed), bool(colsum), _take_gn(x)))
 
 
 def _attach_cs(y):
@@ -1032,7 +1094,7 @@ def _attach_cs(y):
 def conv_linear(x, weight, bias=None, cfg=LINEAR, rowbias=None, residual=None, alpha=1.0, drop_p=0.0, drop_seed=0, colsum=False):
     _cs_last[0] = None
     return _attach_cs(_ConvLinear.apply(x, weight, bias, rowbias, residual, cfg, float(alpha), float(drop_p), int(drop_seed),
-                                        bool(colsum), getattr(x, "_t2v_gn", None)))
+                                        bool(colsum), _take_gn(x)))
 
 
 # --------------------------------------------------------------------------- GroupNorm (+SiLU, +dropout)
@@ -1098,9 +1160,11 @@ class _GroupNorm(torch.autograd.Function):
             nv.call("t2v_gn_finish", cs[0].data_ptr(), ndomains, rpd, Cc, G, bsums.data_ptr(), s)
         else:
             ws = _gn_workspace(ndomains, G, x.device)
+            # (full finetune: per-workgroup partial rows of d gamma / d beta, reduced in fixed order — caller-owned scratch)
+            pgw = torch.empty(int(nv.lib().t2v_gn_bwd_pg_floats(ndomains, rpd, Cc)), dtype=torch.float32, device=x.device) if want_pg else None
             nv.call("t2v_gn_bwd_stats", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ndomains, rpd, Cc, G, sums.data_ptr(),
                     g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed, bsums.data_ptr(), ws.data_ptr(), nv.ptr(dgm),
-                    nv.ptr(dbt), s)
+                    nv.ptr(dbt), nv.ptr(pgw), s)
         dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
         nv.call("t2v_gn_bwd_apply", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, ndomains, rpd, Cc, G,
                 sums.data_ptr(), bsums.data_ptr(), g32.data_ptr(), b32.data_ptr(), eps, silu, drop_p, drop_seed,
@@ -1157,8 +1221,9 @@ class _LayerNorm(torch.autograd.Function):
         dgm = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         dbt = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         dx = torch.empty(rows, Cc, dtype=BF16, device=x.device)
+        pgw = torch.empty(int(nv.lib().t2v_layernorm_bwd_pg_floats(rows, Cc)), dtype=torch.float32, device=x.device) if want_pg else None
         nv.call("t2v_layernorm_bwd", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), Cc, rows, Cc,
-                _f32(gamma).data_ptr(), stats.data_ptr(), nv.ptr(dgm), nv.ptr(dbt), nv.ptr(dres),
+                _f32(gamma).data_ptr(), stats.data_ptr(), nv.ptr(dgm), nv.ptr(dbt), nv.ptr(pgw), nv.ptr(dres),
                 _ld(dres) if dres is not None else 0, nv.stream())
         return dx, dgm.to(gamma.dtype) if want_pg else None, dbt.to(beta.dtype) if want_pg else None, None, None
 

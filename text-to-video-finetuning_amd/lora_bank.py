@@ -26,7 +26,8 @@ MERGE_MAX_RANK = 32      # padded rank window of csrc/lora_merge.hip (RMAX)
 
 class LoraEntry:
     __slots__ = ("r", "rp", "n", "npad", "cin", "cin_p", "taps", "down_off", "up_off", "down_numel", "up_numel",
-                 "down_w16", "up_w16", "down_g", "up_g", "flat_ptr", "group", "gidx", "weff_fwd", "weff_bwd", "merge_scale")
+                 "down_w16", "up_w16", "down_g", "up_g", "flat_ptr", "group", "gidx", "weff_fwd", "weff_bwd", "merge_scale",
+                 "up_t16", "down_t16", "rk", "prep_scale")
 
 
 class LoraGroup:
@@ -354,6 +355,76 @@ class MergePlan:
         self._mark(True)
         from . import native as nv
         nv.call("t2v_lora_merge", self.jobs_dev.data_ptr(), self.njobs, self.tile_job_dev.data_ptr(), self.ntiles, nv.stream())
+
+
+class PrepPlan:
+    """Transposed bf16 factor copies for the wrapped layers whose dropout is ACTIVE (the reference's default train mode,
+    utils/lora.py:35,49,89,119): the branch cannot be merged into W, the base layer's launch adds it in its epilogue instead
+    (T2VGemm.lr_mode; functional._LoraLayer) and reads the factors row-per-output-column:
+      up_t16   bf16 [Np, rk]         = U^T                       forward   y  += s mask (t U^T)
+      down_t16 bf16 [Cin_p, taps*rk] = s D^T, flipped taps       backward  dx += s dt (*) D^T
+    refreshed by ONE `t2v_lora_prep` launch per step (device job table built once; every buffer it points to is allocated
+    once).  `prep_scale` on an entry = the scale baked into its copies while they are current, else None (the layers then take
+    the separate rank-update passes)."""
+
+    def __init__(self, plans, flat_p):
+        from . import native as nv
+        dev = flat_p.device
+        BF16 = torch.bfloat16
+        seen, entries = set(), []
+        for pid, (e, role, mod) in plans.items():
+            if id(e) in seen or not all(hasattr(e, a) for a in ("down_off", "up_off")):
+                continue
+            seen.add(id(e))
+            e.prep_scale = None
+            if e.rp > 32:
+                continue
+            entries.append((e, mod))
+        self.entries = entries
+        jobs = (nv.LoraPrepJob * max(1, len(entries)))()
+        total = 0
+        lib = nv.lib()
+        for k, (e, mod) in enumerate(entries):
+            e.rk = 16 if e.rp <= 16 else 32
+            e.up_t16 = torch.zeros(e.npad, e.rk, dtype=BF16, device=dev)
+            e.down_t16 = torch.zeros(e.cin_p, e.taps * e.rk, dtype=BF16, device=dev)
+            j = jobs[k]
+            if e.group is not None:          # the member's column block of the group's up matrix
+                j.up, j.ldu = flat_p.data_ptr() + 4 * (e.up_off + e.gidx * e.npad), e.group.npad
+            else:
+                j.up, j.ldu = flat_p.data_ptr() + 4 * e.up_off, e.npad
+            j.down = flat_p.data_ptr() + 4 * e.down_off
+            j.upT, j.dnT = e.up_t16.data_ptr(), e.down_t16.data_ptr()
+            j.Np, j.Cp, j.taps, j.rp, j.rk, j.scale = e.npad, e.cin_p, e.taps, e.rp, e.rk, float(mod.scale)
+            j.chunk0 = total
+            total += int(lib.t2v_lora_prep_chunks(e.npad, e.cin_p, e.taps, e.rk))
+        self.njobs, self.total = len(entries), total
+        if self.njobs:
+            self.jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self._scales = [float(mod.scale) for _, mod in entries]
+
+    def wanted(self):
+        for _, mod in self.entries:
+            d = getattr(mod, "dropout", None)
+            if isinstance(d, torch.nn.Dropout) and d.training and d.p > 0.0:
+                return True
+        return False
+
+    def run(self):
+        if not self.njobs:
+            return
+        want = self.wanted()
+        if not torch.cuda.is_current_stream_capturing():
+            for (e, mod), s0 in zip(self.entries, self._scales):
+                if float(mod.scale) != s0:
+                    raise RuntimeError("t2v_amd: a LoRA wrapper's scale changed after the trainer was built "
+                                       f"({s0} -> {float(mod.scale)}); rebuild the optimiser / trainer")
+        for (e, mod), s0 in zip(self.entries, self._scales):
+            e.prep_scale = s0 if want else None
+        if not want:
+            return
+        from . import native as nv
+        nv.call("t2v_lora_prep", self.jobs_dev.data_ptr(), self.njobs, self.total, nv.stream())
 
 
 def is_homed(homes):

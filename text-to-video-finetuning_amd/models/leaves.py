@@ -54,11 +54,20 @@ class _Out(SimpleNamespace):
     pass
 
 
-_seed_state = {"base": 0x5EED, "ctr": 0, "step": 0}
+_seed_state = {"base": 0x5EED, "ctr": 0, "step": 0, "fwd": -1}
 
 
 def set_dropout_seed(seed):
-    _seed_state["base"], _seed_state["ctr"], _seed_state["step"] = int(seed), 0, 0
+    _seed_state["base"], _seed_state["ctr"], _seed_state["step"], _seed_state["fwd"] = int(seed), 0, 0, -1
+
+
+def begin_forward():
+    """A root forward with autograd on begins (UNet3DConditionModel.forward calls this): dropout sites draw a fresh mask per
+    FORWARD, not only per optimisation step — the reference's two separate `unet(...)` calls of a step (train.py:814-834) and the
+    micro-steps of a gradient-accumulation window each see their own masks, like nn.Dropout draws them.  The index counts the
+    forwards since the last optimiser step (0 for the first one: a trainer's stacked two-pass forward keeps its seeds); a
+    checkpoint recompute runs sub-module forwards only, so it repeats the masks of the forward it belongs to."""
+    _seed_state["fwd"] += 1
 
 
 def _next_seed():
@@ -78,6 +87,7 @@ def assign_dropout_names(root):
 def advance_dropout_step():
     """Next optimisation step: new masks for plain eager loops (the trainer's captured step moves the DEVICE epoch instead)."""
     _seed_state["step"] += 1
+    _seed_state["fwd"] = -1
 
 
 def _seed_for(mod, suffix=""):
@@ -86,7 +96,7 @@ def _seed_for(mod, suffix=""):
         return _next_seed()               # stand-alone module (kernel tests): counter protocol
     import zlib
     key = zlib.crc32((name + suffix).encode())
-    return (_seed_state["base"] * 1000003 + key * 97 + _seed_state["step"] * 7919) & 0xFFFFFFFFFFFF
+    return (_seed_state["base"] * 1000003 + key * 97 + _seed_state["step"] * 7919 + max(0, _seed_state["fwd"]) * 104729) & 0xFFFFFFFFFFFF
 
 
 def _drop_p(mod):
@@ -114,7 +124,8 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
             if p == 0.0 or entry.rp in (8, 16, 24, 32, 48, 64, 96):
                 # LoRA branch kept apart from the weight: active dropout (the reference's default train mode), or merge off
                 return F.lora_layer(x, base.weight, base.bias, mod.lora_down.weight, mod.lora_up.weight, cfg, entry,
-                                    float(mod.scale), rowbias, residual, drop_p=p, drop_seed=_seed_for(mod) if p > 0 else 0)
+                                    float(mod.scale), rowbias, residual, drop_p=p, drop_seed=_seed_for(mod) if p > 0 else 0,
+                                    colsum=colsum)
         y = F.conv_linear(x, base.weight, base.bias, cfg, rowbias, residual)
         t = F.conv_linear(x, mod.lora_down.weight, None, cfg)
         sel = getattr(mod, "selector", None)

@@ -120,9 +120,24 @@ class UNet3DConditionModel(nn.Module, ModelMixinLite):
                                "cuda (the CPU restatement used for parity lives in oracle/).")
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
             raise RuntimeError("t2v_amd: ControlNet-style additional residuals are not on the training path")
+        if attention_mask is not None:
+            # the reference threads it to every attention (models/unet_3d_condition.py:419-428); train.py / inference.py never
+            # pass one, and the native attention core has no bias operand: refuse rather than ignore it
+            raise RuntimeError("t2v_amd: attention_mask is not supported by the native attention kernels (the reference's train and "
+                               "inference paths never pass one)")
         up_factor = 2 ** self.num_upsamplers
         if any(s % up_factor != 0 for s in sample.shape[-2:]):
-            raise RuntimeError(f"t2v_amd: latent height/width must be multiples of {up_factor} (got {tuple(sample.shape[-2:])})")
+            # the reference forwards `upsample_size` to its upsamplers in this case (models/unet_3d_condition.py:359-367,470-474:
+            # F.interpolate to the skip's size).  The native upsampler folds an exact nearest-2x into the following conv's gather,
+            # so odd grids are refused.  Every size the reference's own data path produces is a multiple of 64 pixels = 8 latent
+            # cells (configured width / height, and utils/bucketing.py:9-19 moves in steps of 64 from them;
+            # tests/test_host_logic.py::test_bucket_sizes...), i.e. the reference never takes that branch from train.py either.
+            raise RuntimeError(f"t2v_amd: latent height/width must be multiples of {up_factor} (got {tuple(sample.shape[-2:])}); the "
+                               f"reference's `upsample_size` path for odd grids is not built (pixel sizes that are multiples of 64 — "
+                               f"all that train.py's datasets and buckets produce — never reach it)")
+        if torch.is_grad_enabled():
+            from .leaves import begin_forward
+            begin_forward()      # dropout sites draw fresh masks per forward (two unet calls per step in the reference's own loop)
         timesteps = timestep
         if not torch.is_tensor(timesteps):
             timesteps = torch.tensor([timesteps], dtype=torch.int64, device=sample.device)

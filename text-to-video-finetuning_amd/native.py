@@ -40,6 +40,13 @@ class LoraMergeJob(C.Structure):
     ]
 
 
+class LoraPrepJob(C.Structure):
+    _fields_ = [
+        ("up", c_void_p), ("ldu", c_ll), ("down", c_void_p), ("upT", c_void_p), ("dnT", c_void_p),
+        ("Np", c_int), ("Cp", c_int), ("taps", c_int), ("rp", c_int), ("rk", c_int), ("scale", c_float), ("chunk0", c_ll),
+    ]
+
+
 class Gemm(C.Structure):
     _fields_ = [
         ("M", c_int), ("N", c_int), ("K", c_int),
@@ -62,6 +69,9 @@ class Gemm(C.Structure):
         ("colsum", c_void_p), ("cs_mode", c_int), ("cs_domain_rows", c_int),
         ("cs_x", c_void_p), ("cs_ldx", c_ll), ("cs_sums", c_void_p), ("cs_gamma", c_void_p), ("cs_beta", c_void_p),
         ("cs_eps", c_float), ("cs_G", c_int), ("cs_silu", c_int),
+        ("lr_mode", c_int), ("lr_rp", c_int), ("lr_taps", c_int),
+        ("lr_a", c_void_p), ("lr_lda", c_ll), ("lr_b", c_void_p), ("lr_ldb", c_ll),
+        ("lr_scale", c_float), ("lr_drop_p", c_float), ("lr_drop_seed", c_ull),
     ]
 
 
@@ -88,7 +98,7 @@ class Attn(C.Structure):
     ]
 
 
-ABI_VERSION = 4          # include/t2v_abi.h T2V_ABI_VERSION
+ABI_VERSION = 5          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
@@ -98,6 +108,7 @@ SYMBOLS = {
     "t2v_abi_version": ([], c_int),
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_gemm_lr_ok": ([C.POINTER(Gemm)], c_int),
     "t2v_gemm_colsum_rows": ([C.POINTER(Gemm)], c_int),
     "t2v_gn_finish": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "t2v_gemm_w8": ([C.POINTER(Gemm), c_int, c_int, c_int, c_void_p], c_int),
@@ -114,13 +125,15 @@ SYMBOLS = {
     "t2v_gn_apply": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                       c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_gn_bwd_stats": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                          c_float, c_int, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+                          c_float, c_int, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "t2v_gn_bwd_pg_floats": ([c_int, c_int, c_int], c_ll),
+    "t2v_layernorm_bwd_pg_floats": ([c_int, c_int], c_ll),
     "t2v_gn_bwd_apply": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_float, c_int, c_float, c_ull, c_void_p, c_ll, c_void_p], c_int),
     "t2v_layernorm_fwd": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p],
                           c_int),
     "t2v_layernorm_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                           c_void_p, c_void_p, c_ll, c_void_p], c_int),
+                           c_void_p, c_void_p, c_void_p, c_ll, c_void_p], c_int),
     "t2v_attn_fwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_attn_bwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_softmax_rows": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_void_p], c_int),
@@ -128,6 +141,8 @@ SYMBOLS = {
     "t2v_lowrank_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_void_p], c_int),
     "t2v_lowrank_update_drop": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_float, c_ull,
                                  c_void_p], c_int),
+    "t2v_lora_prep_chunks": ([c_int, c_int, c_int, c_int], c_ll),
+    "t2v_lora_prep": ([c_void_p, c_int, c_ll, c_void_p], c_int),
     "t2v_lora_wgrad": ([C.POINTER(LoraWgrad), c_void_p], c_int),
     "t2v_lora_drop_dt": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_ull, c_void_p], c_int),
     "t2v_lora_wgrad_batch_bytes": ([c_int], c_ll),

@@ -50,6 +50,9 @@ def lr_lambda(name="constant", num_warmup_steps=0, num_training_steps=None):
     (the default), "constant_with_warmup", "linear", "cosine"."""
     import math
     w, total = int(num_warmup_steps), num_training_steps
+    if name not in ("constant", "constant_with_warmup", "linear", "cosine"):     # (checked when the schedule is BUILT, not mid-training)
+        raise ValueError(f"unknown lr schedule {name!r} (supported: constant, constant_with_warmup, linear, cosine — the ones the "
+                         f"shipped configs use; diffusers' polynomial / cosine_with_restarts are not restated)")
     if name in ("linear", "cosine") and not total:
         raise ValueError(f"lr schedule {name!r} needs num_training_steps")
 
@@ -151,6 +154,11 @@ class FlatAdamW:
         self.merge = None
         if plans and os.environ.get("T2V_LORA_MERGE", "1") != "0":
             self.merge = lora_bank.MergePlan(plans, self.flat_p)
+        # wrappers whose dropout is active (the reference's default train mode) keep the branch apart: its rank-wide terms ride
+        # in the base layers' epilogues and read transposed factor copies (lora_bank.PrepPlan); T2V_LORA_EPI=0: separate passes
+        self.prep = None
+        if plans and os.environ.get("T2V_LORA_EPI", "1") != "0":
+            self.prep = lora_bank.PrepPlan(plans, self.flat_p)
         self.refresh_bf16()
 
     def _ensure_homed(self):
@@ -165,6 +173,23 @@ class FlatAdamW:
         nv.call("t2v_cast_f32_to_bf16", self.flat_p.data_ptr(), self.flat_p16.data_ptr(), self.numel, nv.stream())
         if self.merge is not None:
             self.merge.run()
+        if self.prep is not None:
+            self.prep.run()
+
+    def state_dict(self):
+        """Optimiser state for checkpoint / resume: the AdamW moments in the flat layout of THIS trainer (same model, same trainable
+        set, same lora_bank plan), the device step counter and `steps_done` — the position of the LR schedule, which the reference
+        restores through its scheduler's state (train.py:606-612)."""
+        return {"steps_done": int(self.steps_done), "numel": int(self.numel), "exp_avg": self.exp_avg.detach().clone(),
+                "exp_avg_sq": self.exp_avg_sq.detach().clone(), "step_count": self.step_count.detach().clone()}
+
+    def load_state_dict(self, sd):
+        if int(sd["numel"]) != int(self.numel):
+            raise RuntimeError(f"t2v_amd: optimiser state of {sd['numel']} elements does not fit this trainer ({self.numel})")
+        self.steps_done = int(sd["steps_done"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count.copy_(sd["step_count"])
 
     def zero_grad(self, set_to_none=False):
         from .functional import clear_bwd_colsums, drop_pending_wgrads
@@ -353,12 +378,23 @@ class DenoiseTrainer:
         at its end (in between the flat buffer just accumulates and the loss is returned as is)."""
         if self._micro == 0:
             self.opt.zero_grad()
-        loss = run()
+            self._window_loss = None
+        try:
+            loss = run()
+        except BaseException:
+            # a failed forward / backward leaves a partial gradient in the flat buffer: the window is abandoned (the next call
+            # starts a new one with zero_grad) instead of being applied at its end
+            self._micro = 0
+            raise
         self._micro += 1
+        # the reference logs / gathers the MEAN loss of the window's micro-steps (accelerate divides each by the window length)
+        self._window_loss = loss if self._window_loss is None else self._window_loss + loss
         if self._micro < self.gas:
             return loss
         self._micro = 0
-        return self._exchange_and_update(loss)
+        mean = self._window_loss / self.gas if self.gas > 1 else loss
+        self._window_loss = None
+        return self._exchange_and_update(mean)
 
     def train_step(self, batch):
         return self._micro_step(lambda: self._fwd_bwd(batch))
