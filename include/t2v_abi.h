@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 5   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
+#define T2V_ABI_VERSION 6   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -140,6 +140,13 @@ typedef struct {
   const void* lr_a; long long lr_lda;
   const void* lr_b; long long lr_ldb;
   float lr_scale; float lr_drop_p; unsigned long long lr_drop_seed;
+  /* ABI v6 — projection groups under lr_mode 2 (to_q / to_k / to_v of an attention read the same input: ONE launch with
+   * N = n * lr_group_cols): the column tiles of member i = n0 / lr_group_cols carry rows [i*lr_rp, (i+1)*lr_rp) of B2 (the members'
+   * down factors back to back), write their t to columns [i*lr_rp, ..) of D2, and draw the mask of member i from its OWN seed
+   * (member 0: lr_drop_seed, members 1, 2: lr_group_seed[0..1]) with index m * lr_group_cols + (n - i*lr_group_cols) — every
+   * member keeps the mask it has as a stand-alone layer.  0: no groups.  lr_mode 1 accepts lr_rp up to 48 (three members' dt
+   * side by side: dx = dy_cat W_cat + s dt_cat D_cat). */
+  int lr_group_cols; unsigned long long lr_group_seed[2];
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
 /* Tile rows BMt of the kernel t2v_gemm will run for this descriptor if that kernel can emit `colsum`, else 0 (deterministic:
@@ -311,6 +318,11 @@ int t2v_lora_wgrad(const T2VLoraWgrad* p, t2v_stream_t stream);
  * size is written.  rp in {8, 16, 24, 32}. */
 int t2v_lora_drop_dt(const void* dy, long long lddy, const void* U, long long ldu, void* dt, long long lddt, long long M, int N,
                      int rp, float drop_p, unsigned long long drop_seed, t2v_stream_t stream);
+/* the same for the nmem <= 3 members of a projection group in ONE launch: member i reads columns [i*N, (i+1)*N) of dy, the up
+ * factor at U + i * u_member_stride (elements), its own seed, and writes columns [i*rp, (i+1)*rp) of dt */
+int t2v_lora_drop_dt_group(const void* dy, long long lddy, const void* U, long long ldu, long long u_member_stride, void* dt,
+                           long long lddt, long long M, int N, int rp, int nmem, float drop_p, const unsigned long long* seeds,
+                           t2v_stream_t stream);
 /* The same for MANY layers in one launch (the train step queues the descriptors of a backward pass and flushes them in a few
  * batches: 568 launches of ~15 us become streaming work without per-layer ramps and tails).  `host_staging` = pinned host
  * memory and `device_table` = device memory, each of t2v_lora_wgrad_batch_bytes(nlayers) bytes, owned by the caller and left
@@ -347,7 +359,7 @@ int t2v_lora_merge(const T2VLoraMergeJob* jobs_dev, int njobs, const int* tile_j
 /* ---- transposed bf16 copies of the LoRA factors of all wrapped layers in ONE launch: the operands of the rank-wide epilogue
  * term of t2v_gemm (T2VGemm.lr_b) when the wrappers' dropout is active and the branch cannot be merged into the weight.
  *   upT[n, j]          = U[j, n]                              bf16 [Np, rk]        (forward: y += s mask (t U^T))
- *   dnT[c, tap*rk + j] = scale * D[j, (taps-1-tap)*Cp + c]    bf16 [Cp, taps*rk]   (backward-data: dx += s dt (*) D^T)
+ *   dnT[c, tap*rkd + j] = scale * D[j, (taps-1-tap)*Cp + c]   bf16 [Cp, taps*rkd]  (backward-data: dx += s dt (*) D^T)
  * rk = 16 (rp <= 16) or 32, ranks >= rp zero.  Device pointers; the job table lives in device memory.  chunk0 = sum of
  * t2v_lora_prep_chunks() of the jobs before this one. */
 typedef struct T2VLoraPrepJob {
@@ -357,8 +369,11 @@ typedef struct T2VLoraPrepJob {
   int Np, Cp, taps, rp, rk;
   float scale;
   long long chunk0;
+  long long ldt;                      /* row stride of dnT in elements (>= taps*rkd; a projection group's members share rows) */
+  int rkd;                            /* ranks per tap in dnT (multiple of 8, >= rp): rk for a layer of its own, the padded rank
+                                         itself for the members of a projection group, whose blocks sit side by side */
 } T2VLoraPrepJob;
-long long t2v_lora_prep_chunks(int Np, int Cp, int taps, int rk);
+long long t2v_lora_prep_chunks(int Np, int Cp, int taps, int rk, int rkd);
 int t2v_lora_prep(const T2VLoraPrepJob* jobs_dev, int njobs, long long total_chunks, t2v_stream_t stream);
 
 /* ---- elementwise ---- */

@@ -1185,7 +1185,7 @@ int g_autotune = -1;
 TuneKey make_key(const T2VGemm& p) {
   TuneKey key;
   memset(&key, 0, sizeof(key));
-  key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = (p.n_split > 0 ? 1 : 0) | (p.lr_mode << 1); key.out_mode = p.out_mode;
+  key.M = p.M; key.N = p.N; key.K = p.K; key.a_mode = p.a_mode; key.n_split = (p.n_split > 0 ? 1 : 0) | (p.lr_mode << 1) | (p.lr_group_cols > 0 ? 8 : 0); key.out_mode = p.out_mode;
   key.has_res = p.R != nullptr; key.batch = p.batch > 1 ? p.batch : 1;
   if (p.a_mode == T2V_A_CONV) { key.KH = p.geom.KH; key.KW = p.geom.KW; key.sy = p.geom.sy; key.tdiv = p.geom.tdiv; key.up = p.geom.up; key.C = p.geom.C; }
   return key;
@@ -1211,8 +1211,9 @@ DmaCfg lr_heuristic_cfg(const T2VGemm& p) {
     T2VGemm q = p;
     q.lr_mode = 0;
     if (lr2) {
-      q.N = p.N + p.lr_rp;
+      q.N = p.N + p.lr_rp * (p.lr_group_cols > 0 ? p.N / p.lr_group_cols : 1);
       q.n_split = p.N;
+      q.lr_group_cols = 0;
     }
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(make_key(q));
@@ -1614,7 +1615,8 @@ extern "C" int t2v_gemm_lr_ok(const T2VGemm* pp) {
   if (!pp || pp->lr_mode == 0) return 0;
   T2VGemm p = *pp;
   if (check_gemm(p) != T2V_OK || !w8_ok(p) || p.alpha != 1.f) return 0;
-  if (p.lr_rp < 8 || p.lr_rp > 32 || p.lr_rp % 8 != 0) return 0;
+  if (p.lr_rp < 8 || p.lr_rp > (p.lr_mode == 1 ? 48 : 32) || p.lr_rp % 8 != 0) return 0;
+  if (p.lr_group_cols != 0 && (p.lr_mode != 2 || p.lr_group_cols % 32 != 0 || p.N % p.lr_group_cols != 0 || p.N / p.lr_group_cols > 3)) return 0;
   if (p.lr_mode == 2 && (p.N < 32 || p.n_split > 0)) return 0;
   return 1;
 }

@@ -143,6 +143,9 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   const bool lr2 = LR && p.lr_mode == 2;
   const int nbase = lr2 ? min(N - n0, nstep) : min(N - n0, tn == ntn - 1 ? BN : nstep);
   const int rk0 = lr2 ? ((nbase + 31) & ~31) : 0x40000000;           // tile-local column of the rank fragment
+  // projection group (lr_group_cols > 0): the tile belongs to member n0 / lr_group_cols (launch_w8: the column step divides it)
+  const int gcols = (lr2 && p.lr_group_cols > 0) ? p.lr_group_cols : 0;
+  const int member = gcols ? n0 / gcols : 0;
   const int ncols = lr2 ? rk0 + 32 : nbase;                          // columns this tile owns (multiple of 8)
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     bool rok = nl < ncols;
     if (lr2) {                                     // (rk0 and nbase are multiples of 8 = WROWS: wave-uniform side)
       second = (wave * WROWS + RPP * i) >= rk0;
-      row = (unsigned)(second ? nl - rk0 : n);
+      row = (unsigned)(second ? nl - rk0 + member * p.lr_rp : n);
       rok = second ? (nl - rk0 < p.lr_rp) : (nl < nbase);
     }
     if (second) b2lane |= 1u << i;
@@ -611,15 +614,18 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   auto rank_phase = [&](int ib0_, auto nb_tag) {
     constexpr int NB = decltype(nb_tag)::value;
     const int half = lane >> 5, l31 = lane & 31;
-    const int rp = p.lr_rp, nk = rp > 16 ? 2 : 1, rkp = nk * 16;
+    const int rp = p.lr_rp, nk = (rp + 15) >> 4, rkp = nk * 16;        // (nk <= 2 in mode 2, <= 3 in mode 1: launch_w8)
     const bool masked = p.lr_drop_p > 0.f;
-    const DropKey dkey = drop_key(masked ? eff_seed(p.lr_drop_seed, p.drop_epoch) : 0ull, p.lr_drop_p);
+    const unsigned long long mseed = member == 0 ? p.lr_drop_seed : p.lr_group_seed[member == 1 ? 0 : 1];
+    const DropKey dkey = drop_key(masked ? eff_seed(mseed, p.drop_epoch) : 0ull, p.lr_drop_p);
+    const unsigned mwidth = gcols ? (unsigned)gcols : (unsigned)N;      // mask row width / column origin of this tile's member
+    const int mcol0 = n0 - member * gcols;
     const float sc = masked ? p.lr_scale / (1.f - p.lr_drop_p) : p.lr_scale;
     const bool direct = !masked && sc == 1.f;
     const bf16_t* LB = (const bf16_t*)p.lr_b;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const bf16x4 zero4 = {0, 0, 0, 0};
-    bf16x8 la[NB][2];
+    bf16x8 la[NB][3];
     unsigned rowg[NB];
 #pragma unroll
     for (int io = 0; io < NB; ++io) rowg[io] = (unsigned)m0 + wr * TM + (ib0_ + io) * 32 + l31;
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       for (int q = 0; q < 4; ++q) {
         float t0 = sc * tmp[4 * q], t1 = sc * tmp[4 * q + 1], t2 = sc * tmp[4 * q + 2], t3 = sc * tmp[4 * q + 3];
         if (masked) {
-          const unsigned long long idx = (unsigned long long)rowg[io] * (unsigned)N + (unsigned)(n0 + col0_of(j) + 8 * q + 4 * half);
+          const unsigned long long idx = (unsigned long long)rowg[io] * mwidth + (unsigned)(mcol0 + col0_of(j) + 8 * q + 4 * half);
           const DropQuad h = drop_quad(dkey, idx >> 2);
           t0 = (h.a & 0xffffu) >= dkey.thr ? t0 : 0.f;
           t1 = (h.a >> 16) >= dkey.thr ? t1 : 0.f;
@@ -659,8 +665,8 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
               for (int e = 0; e < 8; ++e) v[e] = acc[io][jj][8 * ks + e];
               const bf16x8 tv = pack8bf(v);
               xt[((wr * FM + ib0_ + io) * 2 + ks) * 64 + lane] = tv;
-              if (tn == 0 && rowg[io] < (unsigned)M) {       // the saved down-projection of the backward pass
-                bf16_t* tp = (bf16_t*)p.D2 + rowg[io] * (unsigned)p.ldd2 + 16 * ks + 4 * half;
+              if (mcol0 == 0 && rowg[io] < (unsigned)M) {     // (first tile of the layer / member) the saved down-projection
+                bf16_t* tp = (bf16_t*)p.D2 + rowg[io] * (unsigned)p.ldd2 + member * rp + 16 * ks + 4 * half;
                 const bf16x4 lo = {tv[0], tv[1], tv[2], tv[3]}, hi = {tv[4], tv[5], tv[6], tv[7]};
                 if (16 * ks + 4 * half < rp) *(bf16x4*)tp = lo;
                 if (16 * ks + 8 + 4 * half < rp) *(bf16x4*)(tp + 8) = hi;
@@ -725,15 +731,15 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           src = (unsigned)((gn[io] * g.Hv + vy) * g.Wv + vx);
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 3; ++ks)
           la[io][ks] = (v && ks < nk && 16 * ks + 8 * half < rp) ? *(const bf16x8*)(LA + src * (unsigned)p.lr_lda + 16 * ks + 8 * half) : zero8;
       }
     };
-    auto load_lb = [&](int j, int tap, bf16x8(&lb)[2]) {
+    auto load_lb = [&](int j, int tap, bf16x8(&lb)[3]) {
       const bool cok = col0_of(j) + l31 < nbase;
       const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + tap * rkp + 8 * half;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) lb[ks] = (cok && ks < nk) ? *(const bf16x8*)(lbp + 16 * ks) : zero8;
+      for (int ks = 0; ks < 3; ++ks) lb[ks] = (cok && ks < nk) ? *(const bf16x8*)(lbp + 16 * ks) : zero8;
     };
     if (direct) {                                    // no mask, unit scale: the products go straight into the accumulators
       for (int tap = 0; tap < taps; ++tap) {
@@ -741,12 +747,13 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           if (col0_of(j) >= nbase) continue;
-          bf16x8 lb[2];
+          bf16x8 lb[3];
           load_lb(j, tap, lb);
 #pragma unroll
           for (int io = 0; io < NB; ++io) {
             acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], acc[io][j], 0, 0, 0);
             if (nk > 1) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], acc[io][j], 0, 0, 0);
+            if (nk > 2) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[2], la[io][2], acc[io][j], 0, 0, 0);
           }
         }
       }
@@ -755,7 +762,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         if (col0_of(j) >= nbase) continue;
-        bf16x8 lb[2];
+        bf16x8 lb[3];
         load_lb(j, 0, lb);
 #pragma unroll
         for (int io = 0; io < NB; ++io) {
@@ -764,6 +771,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
           tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], tmp, 0, 0, 0);
           if (nk > 1) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], tmp, 0, 0, 0);
+          if (nk > 2) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[2], la[io][2], tmp, 0, 0, 0);
           finish(io, j, tmp);
         }
       }
@@ -1166,8 +1174,10 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   const bool lr2 = LR && p.lr_mode == 2;
   if constexpr (LR) {
     T2V_CHECK_ARG(p.lr_mode == 1 || p.lr_mode == 2, "t2v_gemm_w8: lr_mode %d", p.lr_mode);
-    T2V_CHECK_ARG(p.lr_rp >= 8 && p.lr_rp <= 32 && p.lr_rp % 8 == 0 && p.lr_b && p.lr_ldb % 8 == 0 && p.alpha == 1.f,
-                  "t2v_gemm_w8: rank-wide epilogue term needs a padded rank of 8..32, lr_b and alpha == 1");
+    T2V_CHECK_ARG(p.lr_rp >= 8 && p.lr_rp <= (p.lr_mode == 1 ? 48 : 32) && p.lr_rp % 8 == 0 && p.lr_b && p.lr_ldb % 8 == 0 && p.alpha == 1.f,
+                  "t2v_gemm_w8: rank-wide epilogue term needs a padded rank of 8..32 (mode 1: ..48), lr_b and alpha == 1");
+    T2V_CHECK_ARG(p.lr_group_cols == 0 || (p.lr_mode == 2 && p.lr_group_cols % 32 == 0 && p.N % p.lr_group_cols == 0 && p.N / p.lr_group_cols <= 3),
+                  "t2v_gemm_w8: lr_group_cols (mode 2 only) must divide N into at most 3 members of whole fragments");
     T2V_CHECK_ARG(p.lr_drop_p >= 0.f && p.lr_drop_p < 1.f, "t2v_gemm_w8: lr_drop_p must be in [0, 1)");
     T2V_CHECK_ARG((long long)p.N * p.lr_ldb < 0x7ff00000ll, "t2v_gemm_w8: lr_b too large for 32-bit offsets");
     if (p.lr_mode == 1) {
@@ -1184,7 +1194,7 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
       T2V_CHECK_ARG(KG == 1 || !CS, "t2v_gemm_w8: lr_mode 2 with column statistics needs a configuration without K groups");
       T2V_CHECK_ARG(p.n_split <= 0 && p.B2 && p.D2 && p.ldb2 % 8 == 0 && p.ldd2 % 8 == 0 && p.ldd2 >= p.lr_rp && p.lr_taps <= 1 && p.b2_klen <= 0,
                     "t2v_gemm_w8: lr_mode 2 takes the down factor in B2 / D2 with n_split = 0");
-      T2V_CHECK_ARG((long long)p.lr_rp * p.ldb2 * 2 < 0x7ff00000ll && (long long)p.M * p.ldd2 < 0x7ff00000ll, "t2v_gemm_w8: lr_mode 2 offsets");
+      T2V_CHECK_ARG((long long)p.lr_rp * 3 * p.ldb2 * 2 < 0x7ff00000ll && (long long)p.M * p.ldd2 < 0x7ff00000ll, "t2v_gemm_w8: lr_mode 2 offsets");
       if (CS) splits = 1;                          // the staged epilogue reduces the splits after the rank phase (t2v_gemm never
                                                    // pairs the two: colsum_bm() answers 0 for a split configuration)
     }
@@ -1204,6 +1214,8 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   int ntn = 1;
   if (lr2) {                                       // every tile: up to nstep base columns + one fragment of rank columns
     if (nstep > BN - 32) nstep = BN - 32;
+    if (p.lr_group_cols > 0)                       // a tile never straddles two members of a projection group
+      while (p.lr_group_cols % nstep != 0) nstep -= 32;
     ntn = (p.N + nstep - 1) / nstep;
   } else {
     while ((long long)(ntn - 1) * nstep + BN < p.N) ++ntn;      // the last tile takes up to BN columns

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void lora_prep_kernel(const T2VLoraPrepJob* __
     return;
   }
   r -= nu;
-  const long long per_tap = (long long)J.Cp * cpr_u;
+  const long long per_tap = (long long)J.Cp * (J.rkd / 8);
   const int tap = (int)(r / per_tap);
   r -= (long long)tap * per_tap;
   const int j0 = (int)(r / J.Cp) * 8, c = (int)(r % J.Cp);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void lora_prep_kernel(const T2VLoraPrepJob* __
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     o[e] = (j0 + e < J.rp) ? (short)f2bf(J.scale * J.down[(long long)(j0 + e) * K + (long long)(J.taps - 1 - tap) * J.Cp + c]) : (short)0;
-  *(bf16x8*)((bf16_t*)J.dnT + (long long)c * ((long long)J.taps * J.rk) + (long long)tap * J.rk + j0) = o;
+  *(bf16x8*)((bf16_t*)J.dnT + (long long)c * J.ldt + (long long)tap * J.rkd + j0) = o;
 }
 
 }  // namespace
@@ -164,7 +164,9 @@ extern "C" int t2v_lora_merge(const T2VLoraMergeJob* jobs_dev, int njobs, const 
 }
 
 // chunks of one prep job (host side: the caller accumulates them into T2VLoraPrepJob.chunk0 and the launch's total)
-extern "C" long long t2v_lora_prep_chunks(int Np, int Cp, int taps, int rk) { return ((long long)Np + (long long)Cp * taps) * (rk / 8); }
+extern "C" long long t2v_lora_prep_chunks(int Np, int Cp, int taps, int rk, int rkd) {
+  return (long long)Np * (rk / 8) + (long long)Cp * taps * (rkd / 8);
+}
 
 extern "C" int t2v_lora_prep(const T2VLoraPrepJob* jobs_dev, int njobs, long long total_chunks, t2v_stream_t stream) {
   T2V_CHECK_ARG(jobs_dev && njobs > 0 && total_chunks > 0 && (total_chunks + 255) / 256 < (1ll << 31), "t2v_lora_prep: bad arguments");

@@ -171,8 +171,16 @@ template <int RG>      // rank groups of 16
 __global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ U,
                                                             long long ldu, bf16_t* __restrict__ dt, long long lddt, long long M, int N,
                                                             int rp, int WC, float p, unsigned long long seed_in,
-                                                            const unsigned long long* __restrict__ epoch) {
+                                                            const unsigned long long* __restrict__ epoch, long long u_member_stride,
+                                                            unsigned long long seed1, unsigned long long seed2) {
   __shared__ float red[4][32][RG * 16 + 1];
+  // projection group: blockIdx.y = member (own column block of dy, own up factor, own seed, own rank columns of dt)
+  if (blockIdx.y > 0) {
+    dy += (long long)blockIdx.y * N;
+    U += (long long)blockIdx.y * u_member_stride;
+    dt += (long long)blockIdx.y * rp;
+    seed_in = blockIdx.y == 1 ? seed1 : seed2;
+  }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int WR = 4 / WC, wr = w / WC, wc = w - wr * WC;
   const int li = lane & 15, g4 = lane >> 4;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restr
     for (int j = 0; j < RG; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const int nblk = (N + 63) >> 6;
-  constexpr int UNR = 2;                           // 64-column blocks in flight per wave
+  constexpr int UNR = RG == 1 ? 4 : 2;             // 64-column blocks in flight per wave (N = 320 on two wave columns: one round trip)
   for (int b0 = wc; b0 < nblk; b0 += WC * UNR) {
     bf16x8 a[UNR][2][2], u[UNR][RG][2];
 #pragma unroll
@@ -404,10 +412,12 @@ extern "C" int t2v_lora_wgrad(const T2VLoraWgrad* pp, t2v_stream_t stream) {
   return T2V_OK;
 }
 
-extern "C" int t2v_lora_drop_dt(const void* dy, long long lddy, const void* U, long long ldu, void* dt, long long lddt, long long M,
-                                int N, int rp, float drop_p, unsigned long long drop_seed, t2v_stream_t stream) {
-  T2V_CHECK_ARG(dy && U && dt && M > 0 && N > 0 && N % 8 == 0 && lddy % 8 == 0 && ldu % 8 == 0 && lddt >= rp, "t2v_lora_drop_dt: bad args");
+static int lora_drop_dt_launch(const void* dy, long long lddy, const void* U, long long ldu, long long u_member_stride, void* dt,
+                               long long lddt, long long M, int N, int rp, int nmem, float drop_p, const unsigned long long* seeds,
+                               t2v_stream_t stream) {
+  T2V_CHECK_ARG(dy && U && dt && M > 0 && N > 0 && N % 8 == 0 && lddy % 8 == 0 && ldu % 8 == 0 && lddt >= (long long)rp * nmem, "t2v_lora_drop_dt: bad args");
   T2V_CHECK_ARG(rp >= 8 && rp <= 32 && rp % 8 == 0, "t2v_lora_drop_dt: padded rank must be 8, 16, 24 or 32 (got %d)", rp);
+  T2V_CHECK_ARG(nmem >= 1 && nmem <= 3 && seeds, "t2v_lora_drop_dt: 1..3 members");
   T2V_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "t2v_lora_drop_dt: dropout probability must be in [0, 1)");
   // waves as WR x WC: split the columns over WC waves when the rows alone give too few workgroups, prefer the split that wastes
   // the fewest 64-column blocks
@@ -415,7 +425,7 @@ extern "C" int t2v_lora_drop_dt(const void* dy, long long lddy, const void* U, l
   int best_wc = 1;
   double best = 1e30;
   for (int wc : {1, 2, 4}) {
-    const long long blocks = (M + 32 * (4 / wc) - 1) / (32 * (4 / wc));
+    const long long blocks = (M + 32 * (4 / wc) - 1) / (32 * (4 / wc)) * nmem;
     const int per = (nblk + wc - 1) / wc;
     const double waste = (double)per * wc / nblk;
     const double fill = blocks >= 512 ? 1.0 : 512.0 / (double)blocks;       // under-filled launches: time ~ 1 / blocks
@@ -428,12 +438,24 @@ extern "C" int t2v_lora_drop_dt(const void* dy, long long lddy, const void* U, l
   const int WR = 4 / best_wc;
   const long long blocks = (M + 32 * WR - 1) / (32 * WR);
   T2V_CHECK_ARG(blocks < (1LL << 31), "t2v_lora_drop_dt: too many rows");
+  const unsigned long long s0 = seeds[0], s1 = nmem > 1 ? seeds[1] : 0ull, s2 = nmem > 2 ? seeds[2] : 0ull;
   if (rp <= 16)
-    T2V_LAUNCH(lora_drop_dt_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)U, ldu,
-               (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, drop_seed, t2v_drop_epoch);
+    T2V_LAUNCH(lora_drop_dt_kernel<1>, dim3((unsigned)blocks, (unsigned)nmem), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
+               (const bf16_t*)U, ldu, (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, s0, t2v_drop_epoch, u_member_stride, s1, s2);
   else
-    T2V_LAUNCH(lora_drop_dt_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)U, ldu,
-               (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, drop_seed, t2v_drop_epoch);
+    T2V_LAUNCH(lora_drop_dt_kernel<2>, dim3((unsigned)blocks, (unsigned)nmem), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
+               (const bf16_t*)U, ldu, (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, s0, t2v_drop_epoch, u_member_stride, s1, s2);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
+}
+
+extern "C" int t2v_lora_drop_dt(const void* dy, long long lddy, const void* U, long long ldu, void* dt, long long lddt, long long M,
+                                int N, int rp, float drop_p, unsigned long long drop_seed, t2v_stream_t stream) {
+  return lora_drop_dt_launch(dy, lddy, U, ldu, 0, dt, lddt, M, N, rp, 1, drop_p, &drop_seed, stream);
+}
+
+extern "C" int t2v_lora_drop_dt_group(const void* dy, long long lddy, const void* U, long long ldu, long long u_member_stride, void* dt,
+                                      long long lddt, long long M, int N, int rp, int nmem, float drop_p,
+                                      const unsigned long long* seeds, t2v_stream_t stream) {
+  return lora_drop_dt_launch(dy, lddy, U, ldu, u_member_stride, dt, lddt, M, N, rp, nmem, drop_p, seeds, stream);
 }

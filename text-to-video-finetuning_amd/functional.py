@@ -127,7 +127,18 @@ def resync_prepared(params):
         if not cache:
             continue
         tag = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
-        for kind, (old_tag, buf) in list(cache.items()):
+        for kind, hit in list(cache.items()):
+            if isinstance(kind, tuple):          # ("group", fwd|bwd): concatenated copy of a projection group (cached on its first member)
+                gtag, buf, ws = hit
+                ntag = tuple((m.data_ptr(), m._version, tuple(m.shape)) for m in ws)
+                if ntag != gtag:
+                    if [t[2] for t in ntag] != [t[2] for t in gtag] or buf.device != w.device:
+                        raise RuntimeError("t2v_amd: a frozen parameter changed shape/device under a captured step; re-capture")
+                    buf.copy_(torch.cat([_prep_compute(m, kind[1], None) for m in ws], dim=0 if kind[1] == "fwd" else 1))
+                    cache[kind] = (ntag, buf, ws)
+                    n += 1
+                continue
+            old_tag, buf = hit
             if old_tag != tag:
                 if old_tag[2] != tag[2] or buf.device != w.device:
                     raise RuntimeError("t2v_amd: a frozen parameter changed shape/device under a captured step; re-capture")
@@ -231,6 +242,9 @@ def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0
         g.lr_a, g.lr_lda = lr.get("a"), lr.get("lda", 0)
         g.lr_b, g.lr_ldb = lr["b"], lr["ldb"]
         g.lr_scale, g.lr_drop_p, g.lr_drop_seed = lr.get("scale", 1.0), lr.get("drop_p", 0.0), lr.get("drop_seed", 0)
+        g.lr_group_cols = lr.get("group_cols", 0)
+        for i, sd in enumerate(lr.get("group_seeds", ())[:2]):
+            g.lr_group_seed[i] = sd
     if use_ws and out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
         ws = _gemm_workspace()          # one scratch per device: main-stream launches only (stream order serialises its users)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -694,7 +708,7 @@ class _LoraLayer(torch.autograd.Function):
             kw = dict(M=M, N=cin_p, K=wb.shape[1], A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1], D=dx.data_ptr(),
                       ldd=cin_p, a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.bwd_geom(npad) if conv else None,
                       lr=dict(mode=1, rp=e.rp, taps=cfg.taps(), a=dt.data_ptr(), lda=e.rp, b=e.down_t16.data_ptr(),
-                              ldb=cfg.taps() * e.rk))
+                              ldb=_ld(e.down_t16)))
             if not _lr_ok(kw):
                 kw, dx = None, None
         if kw is not None:
@@ -969,7 +983,7 @@ def _group_weight(ws, kind):
     hit = cache.get(("group", kind))
     if hit is None or hit[0] != tag:
         parts = [prepared_weight(w, kind) for w in ws]
-        hit = (tag, torch.cat(parts, dim=0 if kind == "fwd" else 1).contiguous())
+        hit = (tag, torch.cat(parts, dim=0 if kind == "fwd" else 1).contiguous(), list(ws))
         cache[("group", kind)] = hit
     return hit[1]
 
@@ -1062,6 +1076,91 @@ class _LoraGroup(torch.autograd.Function):
         else:
             wgrads()
         return (dx if need_dx else None, None, None) + (None,) * (3 * n)
+
+
+class _LoraGroupDrop(torch.autograd.Function):
+    """Projections sharing one input (to_q / to_k / to_v, or to_k / to_v of the text cross-attention) with their wrappers' dropout
+    ACTIVE (the reference's default train mode), as ONE layer with the branches in the epilogue (T2VGemm.lr_mode 2 with
+    lr_group_cols): [y_0 | .. | y_{n-1}] = x [W_0; ..]^T + s mask_i (t_i U_i^T), every member with its own seed and mask index —
+    the masks it draws as a stand-alone layer; backward: dt_cat from one masked pass over [dy_0 | ..] (t2v_lora_drop_dt_group),
+    dx = dy_cat W_cat + s dt_cat D_cat in one launch (lr_mode 1, 16 n ranks side by side), factor gradients per member."""
+
+    @staticmethod
+    def forward(ctx, x, g, scale, drop_p, seeds, *params):
+        x = _mat(x, "x")
+        n = g.n
+        w_bases = params[:n]
+        wq = _group_weight(w_bases, "fwd")
+        ncat, K = wq.shape
+        if x.shape[1] != K or ncat != g.npad or K != g.cin_p:
+            raise RuntimeError("t2v_amd: projection group does not match its layers")
+        M = x.shape[0]
+        y = torch.empty(M, ncat, dtype=BF16, device=x.device)
+        t = torch.empty(M, g.rp, dtype=BF16, device=x.device)
+        launch_gemm(M=M, N=ncat, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=ncat,
+                    B2=g.down_w16.data_ptr(), ldb2=K, D2=t.data_ptr(), ldd2=g.rp,
+                    lr=dict(mode=2, rp=g.rp_each, b=g.up_t16.data_ptr(), ldb=g.rk, scale=scale, drop_p=drop_p, drop_seed=seeds[0],
+                            group_cols=g.npad_each, group_seeds=seeds[1:]))
+        ctx.g, ctx.scale, ctx.drop = g, scale, (drop_p, seeds)
+        ctx.save_for_backward(x, t, *w_bases)
+        return tuple(y[:, i * g.npad_each:(i + 1) * g.npad_each] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, t = ctx.saved_tensors[:2]
+        w_bases = ctx.saved_tensors[2:]
+        g, scale = ctx.g, ctx.scale
+        drop_p, seeds = ctx.drop
+        n, M = g.n, x.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        if any(d is None for d in dys):
+            dys = [d if d is not None else torch.zeros(M, g.npad_each, dtype=BF16, device=x.device) for d in dys]
+        if _adjacent_columns(dys):
+            dy_ptr, lddy = dys[0].data_ptr(), dys[0].stride(0)
+            keep = dys
+        else:
+            dcat = torch.cat([_mat(d if d.stride(1) == 1 else d.contiguous(), "dy") for d in dys], dim=1)
+            dy_ptr, lddy = dcat.data_ptr(), dcat.stride(0)
+            keep = (dcat,)
+        cin_p, ncat = g.cin_p, g.npad
+        rpe, npe = g.rp_each, g.npad_each
+        dt = torch.empty(M, g.rp, dtype=BF16, device=x.device)          # dt_i = (mask_i dy_i / (1-p)) U_i, side by side
+        sd = (C.c_ulonglong * 3)(*(list(seeds) + [0] * (3 - n)))
+        nv.call("t2v_lora_drop_dt_group", dy_ptr, lddy, g.up_w16.data_ptr(), _ld(g.up_w16), rpe * _ld(g.up_w16) + npe, dt.data_ptr(), g.rp,
+                M, npe, rpe, n, drop_p, sd, nv.stream())
+        dx = None
+        if need_dx:
+            wb = _group_weight(w_bases, "bwd")
+            dx = torch.empty(M, cin_p, dtype=BF16, device=x.device)
+            launch_gemm(M=M, N=cin_p, K=ncat, A=dy_ptr, lda=lddy, B=wb.data_ptr(), ldb=ncat, D=dx.data_ptr(), ldd=cin_p,
+                        lr=dict(mode=1, rp=g.rp, taps=1, a=dt.data_ptr(), lda=g.rp, b=g.down_t16.data_ptr(), ldb=_ld(g.down_t16)))
+        for i in range(n):
+            w = nv.LoraWgrad()
+            w.rows, w.rp, w.conv = M, rpe, 0
+            w.t, w.ldt = t.data_ptr() + i * rpe * 2, g.rp
+            w.dy, w.lddy, w.N = dy_ptr + i * npe * 2, lddy, npe
+            w.dU, w.lddu = g.up_g.data_ptr() + (i * rpe * ncat + i * npe) * 4, ncat
+            w.dt, w.lddt = dt.data_ptr() + i * rpe * 2, g.rp
+            w.x, w.ldx, w.C = x.data_ptr(), _ld(x), cin_p
+            w.dD, w.lddd = g.down_g.data_ptr() + i * rpe * cin_p * 4, cin_p
+            w.alpha = scale
+            w.drop_p, w.drop_seed = drop_p, seeds[i]
+            _wgrad_launch(w, (t, dt, x, keep))
+        return (dx, None, None, None, None) + (None,) * (3 * n)
+
+
+def lora_group_drop_ok(x, group, scale):
+    """True if the grouped epilogue form applies: transposed factor copies current, batched wgrad path, a descriptor the LR
+    kernels take."""
+    if not (_lora_epi and _drop_fuse and _wq["enabled"] and getattr(group, "prep_scale", None) == float(scale)):
+        return False
+    K = group.cin_p
+    return K % 64 == 0 and group.npad_each % 64 == 0 and x.shape[0] >= _LORA_EPI_MIN_ROWS and x.shape[0] * max(group.npad, K) * 2 < 0x7ff00000
+
+
+def lora_group_drop(x, group, scale, w_bases, drop_p, seeds):
+    factors = [w for m in group.mods for w in (m.lora_down.weight, m.lora_up.weight)]
+    return _LoraGroupDrop.apply(x, group, float(scale), float(drop_p), tuple(int(s) for s in seeds), *w_bases, *factors)
 
 
 def lora_group(x, group, scale, w_bases):

@@ -33,7 +33,7 @@ class LoraEntry:
 class LoraGroup:
     """Projections that share their input (see module docstring).  `n` members of equal (rp, Np, Cin_p)."""
     __slots__ = ("entries", "mods", "owner", "n", "rp_each", "rp", "npad_each", "npad", "cin_p", "down_w16", "up_w16", "down_g",
-                 "up_g", "weff_fwd", "weff_bwd", "merge_scale")
+                 "up_g", "weff_fwd", "weff_bwd", "merge_scale", "up_t16", "down_t16", "rk", "prep_scale")
 
 
 def _dissolve(g):
@@ -384,10 +384,29 @@ class PrepPlan:
         jobs = (nv.LoraPrepJob * max(1, len(entries)))()
         total = 0
         lib = nv.lib()
+        groups = {}
         for k, (e, mod) in enumerate(entries):
             e.rk = 16 if e.rp <= 16 else 32
-            e.up_t16 = torch.zeros(e.npad, e.rk, dtype=BF16, device=dev)
-            e.down_t16 = torch.zeros(e.cin_p, e.taps * e.rk, dtype=BF16, device=dev)
+            g = e.group
+            if g is not None and g.rp_each * g.n <= 48 and e.rk == 16:
+                # members of a projection group: row blocks of ONE up^T buffer [n*Np, rk] and column blocks of ONE (s D)^T buffer
+                # [Cin_p, n*rk] — what the grouped launches read (functional._LoraGroupDrop); a member evaluated on its own
+                # reads its block through the strides
+                # (the (s D)^T blocks sit at stride rp_each — the stride of the members' dt columns in dt_cat, the other operand
+                #  of dx += s dt_cat D_cat; 16 spare columns so that a member read on its own may run 16 ranks wide)
+                if id(g) not in groups:
+                    g.rk = e.rk
+                    g.up_t16 = torch.zeros(g.npad, e.rk, dtype=BF16, device=dev)
+                    g.down_t16 = torch.zeros(g.cin_p, (g.n * g.rp_each + 15) // 16 * 16 + 16, dtype=BF16, device=dev)
+                    g.prep_scale = None
+                    groups[id(g)] = g
+                e.up_t16 = g.up_t16[e.gidx * e.npad:(e.gidx + 1) * e.npad]
+                e.down_t16 = g.down_t16[:, e.gidx * e.rp:]
+                rkd = e.rp
+            else:
+                e.up_t16 = torch.zeros(e.npad, e.rk, dtype=BF16, device=dev)
+                e.down_t16 = torch.zeros(e.cin_p, e.taps * e.rk, dtype=BF16, device=dev)
+                rkd = e.rk
             j = jobs[k]
             if e.group is not None:          # the member's column block of the group's up matrix
                 j.up, j.ldu = flat_p.data_ptr() + 4 * (e.up_off + e.gidx * e.npad), e.group.npad
@@ -396,12 +415,14 @@ class PrepPlan:
             j.down = flat_p.data_ptr() + 4 * e.down_off
             j.upT, j.dnT = e.up_t16.data_ptr(), e.down_t16.data_ptr()
             j.Np, j.Cp, j.taps, j.rp, j.rk, j.scale = e.npad, e.cin_p, e.taps, e.rp, e.rk, float(mod.scale)
+            j.ldt, j.rkd = e.down_t16.stride(0), rkd
             j.chunk0 = total
-            total += int(lib.t2v_lora_prep_chunks(e.npad, e.cin_p, e.taps, e.rk))
+            total += int(lib.t2v_lora_prep_chunks(e.npad, e.cin_p, e.taps, e.rk, rkd))
         self.njobs, self.total = len(entries), total
         if self.njobs:
             self.jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         self._scales = [float(mod.scale) for _, mod in entries]
+        self.groups = list(groups.values())
 
     def wanted(self):
         for _, mod in self.entries:
@@ -421,6 +442,8 @@ class PrepPlan:
                                        f"({s0} -> {float(mod.scale)}); rebuild the optimiser / trainer")
         for (e, mod), s0 in zip(self.entries, self._scales):
             e.prep_scale = s0 if want else None
+        for g in self.groups:
+            g.prep_scale = float(g.mods[0].scale) if want else None
         if not want:
             return
         from . import native as nv

@@ -300,10 +300,12 @@ class Attention(nn.Module):
         g = self.__dict__.get("_t2v_group")
         if g is None or not torch.is_grad_enabled() or g.n != (3 if self_attention else 2):
             return None
+        p0 = _drop_p(getattr(g.mods[0], "dropout", None))
         for m in g.mods:
             base = m.linear
             sel = getattr(m, "selector", None)
-            if (_drop_p(getattr(m, "dropout", None)) != 0.0 or base.weight.requires_grad or base.bias is not None
+            # (dropout: all members off, or all on with one rate — the grouped epilogue form, functional.lora_group_drop)
+            if (_drop_p(getattr(m, "dropout", None)) != p0 or base.weight.requires_grad or base.bias is not None
                     or not (sel is None or isinstance(sel, nn.Identity)) or float(m.scale) != float(g.mods[0].scale)
                     or getattr(m, "_t2v_bank", None) is None):
                 return None
@@ -312,14 +314,23 @@ class Attention(nn.Module):
     def forward(self, x, qlay, ctx=None, klay=None, residual=None):
         src = x if ctx is None else ctx
         g = self._fused_group(ctx is None)
+        if g is not None:
+            p0 = _drop_p(getattr(g.mods[0], "dropout", None))
+            if p0 > 0.0 and not F.lora_group_drop_ok(src, g, g.mods[0].scale):
+                g = None                 # dropping members without the grouped epilogue form: one by one (run_layer)
         merged = g is not None and getattr(g, "merge_scale", None) == float(g.mods[0].scale)
+
+        def group(inp):
+            if p0 > 0.0:
+                return F.lora_group_drop(inp, g, g.mods[0].scale, [m.linear.weight for m in g.mods], p0, [_seed_for(m) for m in g.mods])
+            if merged:
+                return F.lora_group_merged(inp, g, g.mods[0].scale)
+            return F.lora_group(inp, g, g.mods[0].scale, [m.linear.weight for m in g.mods])
         if g is not None and ctx is None:
-            q, k, v = (F.lora_group_merged(x, g, g.mods[0].scale) if merged else
-                       F.lora_group(x, g, g.mods[0].scale, [m.linear.weight for m in g.mods]))
+            q, k, v = group(x)
         elif g is not None:
             q = run_layer(self.to_q, x)
-            k, v = (F.lora_group_merged(src, g, g.mods[0].scale) if merged else
-                    F.lora_group(src, g, g.mods[0].scale, [m.linear.weight for m in g.mods]))
+            k, v = group(src)
         else:
             q = run_layer(self.to_q, x)
             k = run_layer(self.to_k, src)

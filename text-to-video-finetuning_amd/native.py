@@ -44,6 +44,7 @@ class LoraPrepJob(C.Structure):
     _fields_ = [
         ("up", c_void_p), ("ldu", c_ll), ("down", c_void_p), ("upT", c_void_p), ("dnT", c_void_p),
         ("Np", c_int), ("Cp", c_int), ("taps", c_int), ("rp", c_int), ("rk", c_int), ("scale", c_float), ("chunk0", c_ll),
+        ("ldt", c_ll), ("rkd", c_int),
     ]
 
 
@@ -72,6 +73,7 @@ class Gemm(C.Structure):
         ("lr_mode", c_int), ("lr_rp", c_int), ("lr_taps", c_int),
         ("lr_a", c_void_p), ("lr_lda", c_ll), ("lr_b", c_void_p), ("lr_ldb", c_ll),
         ("lr_scale", c_float), ("lr_drop_p", c_float), ("lr_drop_seed", c_ull),
+        ("lr_group_cols", c_int), ("lr_group_seed", c_ull * 2),
     ]
 
 
@@ -98,7 +100,7 @@ class Attn(C.Structure):
     ]
 
 
-ABI_VERSION = 5          # include/t2v_abi.h T2V_ABI_VERSION
+ABI_VERSION = 6          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
@@ -141,10 +143,12 @@ SYMBOLS = {
     "t2v_lowrank_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_void_p], c_int),
     "t2v_lowrank_update_drop": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_float, c_ull,
                                  c_void_p], c_int),
-    "t2v_lora_prep_chunks": ([c_int, c_int, c_int, c_int], c_ll),
+    "t2v_lora_prep_chunks": ([c_int, c_int, c_int, c_int, c_int], c_ll),
     "t2v_lora_prep": ([c_void_p, c_int, c_ll, c_void_p], c_int),
     "t2v_lora_wgrad": ([C.POINTER(LoraWgrad), c_void_p], c_int),
     "t2v_lora_drop_dt": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_float, c_ull, c_void_p], c_int),
+    "t2v_lora_drop_dt_group": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_float,
+                                C.POINTER(c_ull), c_void_p], c_int),
     "t2v_lora_wgrad_batch_bytes": ([c_int], c_ll),
     "t2v_lora_wgrad_batch": ([C.POINTER(LoraWgrad), c_int, c_void_p, c_void_p, c_ll, c_void_p], c_int),
     "t2v_lowrank_window_update": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, C.POINTER(ConvGeom), c_ll, c_int, c_int,
