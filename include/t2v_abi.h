@@ -147,6 +147,10 @@ typedef struct {
    * member keeps the mask it has as a stand-alone layer.  0: no groups.  lr_mode 1 accepts lr_rp up to 48 (three members' dt
    * side by side: dx = dy_cat W_cat + s dt_cat D_cat). */
   int lr_group_cols; unsigned long long lr_group_seed[2];
+  /* colsum mode 2 for a norm that DROPS behind its SiLU (TemporalConvLayer's GroupNorm -> SiLU -> Dropout(0.1),
+   * models/unet_3d_blocks.py:312: t2v_gn_apply's drop_p): the incoming gradient is masked first, dz = keep(cs_drop_seed,
+   * m * Nb + n) ? y / (1 - cs_drop_p) : 0 — what t2v_gn_bwd_stats does with its drop_p / drop_seed.  0: no dropout. */
+  float cs_drop_p; unsigned long long cs_drop_seed;
 } T2VGemm;
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
 /* Tile rows BMt of the kernel t2v_gemm will run for this descriptor if that kernel can emit `colsum`, else 0 (deterministic:

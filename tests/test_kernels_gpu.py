@@ -1136,17 +1136,18 @@ def test_gemm_epilogue_groupnorm_statistics(M, C_, K, taps, rpd, res, force):
         nv.call("t2v_gn_stats", x.data_ptr(), C_, nd, rpd, C_, G, fs.data_ptr(), ws.data_ptr(), nv.stream())
         kw2 = dict(kw)
         kw2["R"], kw2["ldr"] = None, 0
-        for silu in (1, 0):
+        for silu, dp, dseed in ((1, 0.0, 0), (0, 0.0, 0), (1, 0.1, 0xD50F)):      # (last: a norm that drops behind its SiLU)
             info = F.launch_gemm(cs={"mode": 2, "x": x.data_ptr(), "ldx": C_, "sums": fs.data_ptr(), "gamma": gamma.data_ptr(),
-                                     "beta": beta.data_ptr(), "eps": 1e-5, "G": G, "silu": silu, "domain_rows": rpd}, **kw2)
+                                     "beta": beta.data_ptr(), "eps": 1e-5, "G": G, "silu": silu, "domain_rows": rpd,
+                                     "drop_p": dp, "drop_seed": dseed}, **kw2)
             assert info is not None
             bs = torch.empty(nd * G * 2, device="cuda")
             nv.call("t2v_gn_finish", info[0].data_ptr(), nd, rpd, C_, G, bs.data_ptr(), nv.stream())
             bref = torch.empty_like(bs)
             nv.call("t2v_gn_bwd_stats", x.data_ptr(), C_, d.data_ptr(), C_, nd, rpd, C_, G, fs.data_ptr(), gamma.data_ptr(),
-                    beta.data_ptr(), 1e-5, silu, 0.0, 0, bref.data_ptr(), ws.data_ptr(), None, None, None, nv.stream())
+                    beta.data_ptr(), 1e-5, silu, dp, dseed, bref.data_ptr(), ws.data_ptr(), None, None, None, nv.stream())
             torch.cuda.synchronize()
-            assert relerr(bs, bref) < 1e-4, silu
+            assert relerr(bs, bref) < 1e-4, (silu, dp)
     finally:
         del os.environ["T2V_GEMM_FORCE_CFG"]
 

@@ -8,12 +8,21 @@
 struct CsState {
   float s1[8], s2[8];               // running sums of this thread's columns
   float mu[8], rs[8], g[8], b[8];   // mode 2: forward statistics and affine terms of the norm, per column
+  DropKey dk;                       // mode 2 with cs_drop_p > 0: the dropout the norm applies behind its SiLU (TemporalConvLayer)
+  float ks;
+  int width;
 };
 
 // `active`: this thread writes base-output columns col..col+7 of a tile whose rows start at m0 (inside ONE domain)
 __device__ __forceinline__ void cs_init(CsState& c, const T2VGemm& p, int mode, bool active, long long m0, int col, int Nb) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) c.s1[e] = c.s2[e] = c.mu[e] = c.rs[e] = c.g[e] = c.b[e] = 0.f;
+  c.ks = 1.f;
+  c.width = Nb;
+  if (mode == 2 && p.cs_drop_p > 0.f) {
+    c.dk = drop_key(eff_seed(p.cs_drop_seed, p.drop_epoch), p.cs_drop_p);
+    c.ks = 1.f / (1.f - p.cs_drop_p);
+  }
   if (mode == 2 && active) {
     const int cpg = Nb / p.cs_G;
     const int dom = (int)(m0 / p.cs_domain_rows);
@@ -31,8 +40,10 @@ __device__ __forceinline__ void cs_init(CsState& c, const T2VGemm& p, int mode, 
   }
 }
 
-// one stored row chunk: ov = the bf16 values just written; xrow (mode 2) = the norm's input at the same place
-__device__ __forceinline__ void cs_add(CsState& c, int mode, const bf16x8& ov, const bf16x8& xrow, int silu) {
+// one stored row chunk: ov = the bf16 values just written; xrow (mode 2) = the norm's input at the same place; (row, col) = the
+// chunk's position in the norm's [rows, C] matrix (the dropout mask index, t2v_gn_bwd_stats' protocol); drop: cs_drop_p > 0
+__device__ __forceinline__ void cs_add(CsState& c, int mode, const bf16x8& ov, const bf16x8& xrow, int silu, unsigned row = 0,
+                                       int col = 0, bool drop = false) {
   if (mode == 1) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -41,10 +52,12 @@ __device__ __forceinline__ void cs_add(CsState& c, int mode, const bf16x8& ov, c
       c.s2[e] += q * q;
     }
   } else if (mode == 2) {                          // the two sums of gn_stats_kernel<true> (norm.hip), same arithmetic
+    const unsigned kb = drop ? drop_bits8(c.dk, (unsigned long long)row * (unsigned)c.width + (unsigned)col) : 0xffu;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float xh = (bf2f((unsigned short)xrow[e]) - c.mu[e]) * c.rs[e];
       float dz = bf2f((unsigned short)ov[e]);
+      if (drop) dz = ((kb >> e) & 1u) ? dz * c.ks : 0.f;
       if (silu) {
         const float zz = xh * c.g[e] + c.b[e];
         const float sg = sigmoid_f(zz);

@@ -339,7 +339,7 @@ __device__ __forceinline__ void epilogue_lean(const T2VGemm& p, f32x16 (&acc)[BM
       if (cs_mode != 0) {
         bf16x8 xrow = ov;
         if (cs_mode == 2) xrow = *(const bf16x8*)((const bf16_t*)p.cs_x + row * (unsigned)p.cs_ldx + col);
-        cs_add(cst, cs_mode, ov, xrow, p.cs_silu);
+        cs_add(cst, cs_mode, ov, xrow, p.cs_silu, row, col, cs_mode == 2 && p.cs_drop_p > 0.f);
       }
     }
   }

@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
         const bf16x8 ov = pack8bf(v);
         *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + col) = ov;
-        if (cs_mode != 0) cs_add(cst, cs_mode, ov, rv[it], p.cs_silu);
+        if (cs_mode != 0) cs_add(cst, cs_mode, ov, rv[it], p.cs_silu, row, col, cs_mode == 2 && p.cs_drop_p > 0.f);
       }
       }
     }

@@ -197,6 +197,7 @@ def launch_gemm(cs=None, **kw):
                 g.cs_x, g.cs_ldx = cs["x"], cs["ldx"]
                 g.cs_sums, g.cs_gamma, g.cs_beta = cs["sums"], cs["gamma"], cs["beta"]
                 g.cs_eps, g.cs_G, g.cs_silu = cs["eps"], cs["G"], cs["silu"]
+                g.cs_drop_p, g.cs_drop_seed = cs.get("drop_p", 0.0), cs.get("drop_seed", 0)
             out = (buf, bm, kw["M"], nb)
     nv.call("t2v_gemm", C.byref(g), nv.stream())
     return out
@@ -394,10 +395,12 @@ def _take_gn(x):
 def _gn_bwd_request(gn, M, C_):
     """Column-statistics request for a backward-data launch whose result is the gradient of a GroupNorm output `gn` recorded:
     the two sums of t2v_gn_bwd_stats ride in the epilogue (mode 2).  None when the record does not fit this launch."""
-    if gn is None or gn.get("uses", 1) != 1 or gn["drop_p"] > 0.0 or gn["x"].shape != (M, C_) or gn["want_pg"]:
+    if gn is None or gn.get("uses", 1) != 1 or gn["x"].shape != (M, C_) or gn["want_pg"]:
         return None
+    # (a norm that drops behind its SiLU — TemporalConvLayer — hands its mask over: cs_drop_p / cs_drop_seed, round 4)
     return {"mode": 2, "x": gn["x"].data_ptr(), "ldx": _ld(gn["x"]), "sums": gn["sums"].data_ptr(), "gamma": gn["g32"].data_ptr(),
-            "beta": gn["b32"].data_ptr(), "eps": gn["eps"], "G": gn["G"], "silu": gn["silu"], "domain_rows": gn["rpd"]}
+            "beta": gn["b32"].data_ptr(), "eps": gn["eps"], "G": gn["G"], "silu": gn["silu"], "domain_rows": gn["rpd"],
+            "drop_p": gn["drop_p"], "drop_seed": gn["drop_seed"]}
 
 
 def _note_bwd_cs(dx, info):
@@ -1231,7 +1234,7 @@ class _GroupNorm(torch.autograd.Function):
         ctx.args = (G, eps, int(silu), ndomains, rpd, drop_p, drop_seed)
         ctx.save_for_backward(x, gamma, beta, sums)
         # forward record for the layer that consumes y: its backward-data launch can then carry this norm's backward sums
-        _gn_last[0] = dict(x=x, sums=sums, g32=g32, b32=b32, G=G, eps=eps, silu=int(silu), rpd=rpd, drop_p=drop_p,
+        _gn_last[0] = dict(x=x, sums=sums, g32=g32, b32=b32, G=G, eps=eps, silu=int(silu), rpd=rpd, drop_p=drop_p, drop_seed=drop_seed,
                            want_pg=bool(gamma.requires_grad or beta.requires_grad))
         if passthrough:          # second output: x itself, for the residual use — its gradient is summed inside bwd_apply
             return y, x.detach()
@@ -1254,8 +1257,7 @@ class _GroupNorm(torch.autograd.Function):
         dbt = torch.zeros(Cc, dtype=torch.float32, device=x.device) if want_pg else None
         bsums = torch.empty(ndomains * G * 2, dtype=torch.float32, device=x.device)
         cs = _bwd_cs.pop(dy.data_ptr(), None)
-        if (cs is not None and not want_pg and drop_p == 0.0 and cs[2] == rows and cs[3] == Cc and rpd % cs[1] == 0
-                and _ld(dy) == Cc):
+        if (cs is not None and not want_pg and cs[2] == rows and cs[3] == Cc and rpd % cs[1] == 0 and _ld(dy) == Cc):
             nv.call("t2v_gn_finish", cs[0].data_ptr(), ndomains, rpd, Cc, G, bsums.data_ptr(), s)
         else:
             ws = _gn_workspace(ndomains, G, x.device)

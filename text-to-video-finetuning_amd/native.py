@@ -74,6 +74,7 @@ class Gemm(C.Structure):
         ("lr_a", c_void_p), ("lr_lda", c_ll), ("lr_b", c_void_p), ("lr_ldb", c_ll),
         ("lr_scale", c_float), ("lr_drop_p", c_float), ("lr_drop_seed", c_ull),
         ("lr_group_cols", c_int), ("lr_group_seed", c_ull * 2),
+        ("cs_drop_p", c_float), ("cs_drop_seed", c_ull),
     ]
 
 
