@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-default-mode", "--no-other-mode", dest="no_default_mode", action="store_true",
                     help="skip the extra short run in the OTHER dropout mode (eval_train beside the default-mode headline, or the "
                          "default mode beside an --eval-train line) that fills config.eval_train_ms_per_step / default_mode_ms_per_step")
+    ap.add_argument("--no-host-timing", action="store_true",
+                    help="skip the five extra steps that measure config.host_ms_per_step (profiling scripts: the trace then ends with "
+                         "exactly the timed replays)")
     ap.add_argument("--export-tune-table", default=None,
                     help="write the GEMM tile table after the run (use with T2V_GEMM_AUTOTUNE=live; scripts/tune_gemm_table.sh)")
     return ap.parse_args()
@@ -407,29 +410,29 @@ def gemm_roofline(trainer, batch):
 
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel family in the step AS IT RUNS (every tile the shipped table selects),
-    from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r03_pmc_step.json: rocprofv3 --pmc
+    from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r04_pmc_step.json: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE, separate passes; PMC collection is slow and never part of the timed bench)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_step.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_step.json")) as f:
             j = json.load(f)
         fam = next(v for k, v in j["families"].items() if k.startswith("gemm_kernel_dma"))
         return {"kernel_family": "gemm_kernel_dma<...> + gemm_w8_kernel<...>: all forward / backward-data launches of one C2 step",
                 "hbm_bytes_per_launch": fam["hbm_bytes_per_launch"], "hbm_GB_per_step": fam["hbm_GB_per_step"],
                 "launches_per_step": fam["launches_per_step"], "fetch_correction": j["fetch_correction"],
-                "source": "profiles/r03_pmc_step.json"}
+                "source": "profiles/r04_pmc_step.json"}
     except Exception:   # noqa: BLE001
         return None
 
 
 def rocprof_family_time(algorithmic_flops):
     """The same family's kernel time in the steady-state GRAPH REPLAY of this bench, from the committed rocprofv3 kernel trace
-    (scripts/profile_bench.sh -> profiles/r03_bench_c2_kernel_stats.txt; pure kernel durations, no per-launch dispatch gap).
+    (scripts/profile_bench.sh -> profiles/r04_bench_c2_kernel_stats.txt; pure kernel durations, no per-launch dispatch gap).
     The live event pairs of the eager instrumented pass above also contain each launch's dispatch latency (~5 us x 955), which a
     graph replay overlaps with the previous kernel; both numbers are reported."""
     try:
         ms = 0.0
         n = 0
-        with open(os.path.join(ROOT, "profiles", "r03_bench_c2_kernel_stats.txt")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_bench_c2_kernel_stats.txt")) as f:
             for line in f:
                 if ("gemm_kernel_dma" in line or "gemm_w8_kernel" in line) and line.lstrip().startswith("_Z"):
                     parts = line.split()
@@ -439,7 +442,7 @@ def rocprof_family_time(algorithmic_flops):
             return None
         tf = algorithmic_flops / (ms * 1e-3) / 1e12
         return {"kernel_ms_per_step": round(ms, 2), "launches_per_step": n, "TFLOP/s": round(tf, 1),
-                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "source": "profiles/r03_bench_c2_kernel_stats.txt (config c2)"}
+                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "source": "profiles/r04_bench_c2_kernel_stats.txt (config c2)"}
     except Exception:   # noqa: BLE001
         return None
 
@@ -624,13 +627,13 @@ def main():
     # the step rate at N > 1 once the device work shrinks (a replay of a still-running graph blocks the host, so the loop above
     # cannot show it); median of 5
     hs = []
-    for _ in range(5):
+    for _ in range(0 if args.no_host_timing else 5):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         loss = step()
         hs.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
-    host_ms = round(sorted(hs)[2] * 1e3, 3)
+    host_ms = round(sorted(hs)[2] * 1e3, 3) if hs else None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

@@ -12,7 +12,8 @@ import re
 import sys
 
 GEMM_LABEL = "gemm_kernel_dma<...> + gemm_w8_kernel<...> (Linear / Conv2d / Conv3d forward + backward-data, LDS-DMA ring)"
-FAMILIES = [("gemm_kernel_dma", GEMM_LABEL), ("gemm_w8_kernel", GEMM_LABEL),
+FAMILIES = [("gemm_kernel_dma", GEMM_LABEL), ("gemm_w8_kernel", GEMM_LABEL), ("lora_drop_dt", "lora_drop_dt_kernel (masked dt of the dropped LoRA branches)"),
+            ("lora_prep", "lora_prep_kernel"),
             ("gemm_kernel<", "gemm_kernel<..,AT|BT> (K-major operands)"), ("gemm_pair", "gemm_pair_kernel"),
             ("gemm_finalize", "gemm_finalize_kernel (split-K)"), ("lora_wgrad", "lora_wgrad_kernel (factor gradients)"),
             ("lora_merge", "lora_merge_kernel"), ("gn_stats_kernelILb0", "gn_stats (forward)"), ("gn_stats_kernelILb1", "gn_stats (backward)"),
@@ -48,8 +49,11 @@ def main():
     base, dst = sys.argv[1], sys.argv[2]
     f, w = parse(base + "_FETCH_SIZE.txt"), parse(base + "_WRITE_SIZE.txt")
     # executions of the step in the profiled command: the LoRA merge kernel runs exactly once per step
+    # steps inside the counted window: scripts/pmc_step.sh appends it ("steps_in_window N"); older logs: the LoRA merge kernel runs
+    # exactly once per step
     once = [v[0] for k, v in f.items() if "lora_merge_kernel" in k]
-    execs = int(sys.argv[3]) if len(sys.argv) > 3 else (once[0] if once else 4)
+    win = re.search(r"steps_in_window (\d+)", open(base + "_FETCH_SIZE.txt").read())
+    execs = int(sys.argv[3]) if len(sys.argv) > 3 else (int(win.group(1)) if win else (once[0] if once else 4))
     fam = {}
     for name in set(f) | set(w):
         label = demangle_family(name)
@@ -71,8 +75,9 @@ def main():
                            hbm_GB_per_step=round((read_b + write_b) / execs / 1e9, 2),
                            GBps_while_running=round((read_b + write_b) / d["us"] / 1e3, 1))
     out = dict(what="rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes, scripts/pmc_step.sh) over "
-                    "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-default-mode` (config C2, shipped tile table, HIP-graph "
-                    f"replay): {execs} executions of the step; per-kernel-family totals",
+                    "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-default-mode --no-host-timing` (config C2 in the reference's "
+                    f"default train mode, shipped tile table, HIP-graph replay): the last {execs} steps of the trace (the timed replays); "
+                    "per-kernel-family totals",
                fetch_correction="reads = 2 x FETCH_SIZE: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16 B/lane streaming "
                                 "read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both in KB",
                families=rows)
