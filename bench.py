@@ -561,7 +561,11 @@ def main():
     import t2v_amd  # noqa: F401
     from t2v_amd.parallel import init_from_env
     from t2v_amd.training import DenoiseTrainer
-    rank, world, local = init_from_env("nccl" if args.gpus > 1 else None)
+    # (T2V_BENCH_BACKEND=gloo + T2V_BENCH_SHARE_GPU=1: two ranks on ONE device over gloo — the plumbing test of tests/test_dp_gpu.py;
+    #  RCCL refuses two ranks on one GPU)
+    rank, world, local = init_from_env(os.environ.get("T2V_BENCH_BACKEND", "nccl") if args.gpus > 1 else None)
+    if os.environ.get("T2V_BENCH_SHARE_GPU") == "1":
+        local = local % max(1, torch.cuda.device_count())
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():

@@ -3,7 +3,8 @@
 
     python tests/golden/make_oracle_step.py --config c1 --scales 0,0.02,0.2
     python tests/golden/make_oracle_step.py --config c2 --scales 0.02
-    python tests/golden/make_oracle_step.py --config c3            (full finetune: gradients of all 1.41 B UNet parameters)
+    python tests/golden/make_oracle_step.py --config c3            (full finetune: gradients of all 1.41 B UNet parameters, C1 clip)
+    python tests/golden/make_oracle_step.py --config c3full        (the same on configs[2]'s own clip: 16 frames @256x256)
     python tests/golden/make_oracle_step.py --config c1 --scales 0.02 --dropout   (default train mode, restated masks)
     python tests/golden/make_oracle_step.py --config c2 --scales 0.02 --dropout   (the same at the benchmark configuration)
 
@@ -67,11 +68,11 @@ def main():
     import parity_utils as pu
     frames, H, W, r = pu.CONFIGS[args.config]
     from oracle.weights import synthetic_batch
-    if args.config == "c3":            # full finetune: one fixture (no LoRA factors to scale)
+    if args.config in ("c3", "c3full"):            # full finetune: one fixture (no LoRA factors to scale)
         args.scales = "0"
     for scale in [float(s) for s in args.scales.split(",")]:
         t0 = time.time()
-        if args.config == "c3":
+        if args.config in ("c3", "c3full"):
             unet, vae = pu.build_oracle_full_finetune(True)
             n_wrapped = 0
         else:
@@ -83,7 +84,7 @@ def main():
             pu.enable_reference_dropout(unet)
             # first _fwd_bwd of a fresh trainer: device epoch = (rank << 32) + 2, host step 0 (tests/test_lora_grads_gpu.py)
             ctx = odrop.install_protocol(unet, pu.DROPOUT_BASE_SEED, step=0, epoch=2, batch=1, frames=frames, passes=2)
-        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config == "c2" and not args.dropout),
+        loss, grads = pu.oracle_loss_and_grads(unet, vae, batch, single_pass_doubled=(args.config in ("c2", "c3full") and not args.dropout),
                                                sequential_passes=(args.config == "c2" and args.dropout))
         if args.dropout:
             assert ctx["k"] == 1, "both passes must have run through the protocol"

@@ -20,6 +20,9 @@ CONFIGS = {            # BASELINE.json configs: name -> (frames, H, W, lora rank
     # fixture is taken on the C1 clip: the weight-gradient layouts under test do not depend on the clip size, and the CPU
     # oracle's full-size backward stays at minutes / tens of GB
     "c3": (8, 128, 128, 0),
+    # the same on configs[2]'s OWN clip (16 frames @256x256; round 4): one oracle pass, doubled (the passes are identical with a frozen
+    # text encoder and no dropout) — ~10 min and ~45 GB on the build host
+    "c3full": (16, 256, 256, 0),
 }
 
 

@@ -184,3 +184,24 @@ def test_rccl_allreduce_of_the_flat_gradient_buffer_around_a_graph_replay():
         assert torch.isfinite(l1) and float(l0) > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_gpus_2_self_spawns_and_prints_one_line():
+    """`python bench.py --gpus 2` without a rendezvous environment re-launches itself under torch.distributed.run (bench._self_spawn:
+    what the driver's multi-GPU run relies on when it starts the script directly).  Two ranks share the one device of this box
+    over gloo (RCCL refuses two ranks on one GPU): rank 0 must print ONE json line with n_gpus = 2 and the whole-job rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, T2V_BENCH_BACKEND="gloo", T2V_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c1",
+                          "--no-cpu-baseline", "--no-roofline", "--no-other-mode"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]       # whole-job rate: both ranks' clips per step time

@@ -550,3 +550,27 @@ def test_lr_schedules_follow_the_reference_options():
     import pytest
     with pytest.raises(ValueError):
         lr_lambda("linear", 2)
+
+
+def test_bucket_sizes_of_the_reference_are_whole_latent_octets():
+    """`utils/bucketing.py:22-32` (executed from /root/reference by tests/golden/make_golden.py -> buckets.json): starting from a
+    configured width / height that is a multiple of 64 pixels, every bucket the reference's datasets resize to is again a multiple
+    of 64 pixels = 8 latent cells.  That is why the native UNet may refuse latent grids that are not multiples of 2**num_upsamplers
+    (the reference's `upsample_size` branch, models/unet_3d_condition.py:359-367, is never reached from train.py)."""
+    import json
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "buckets.json")))
+    assert len(cases) >= 4
+    for c in cases:
+        mw, mh = c["args"][:2]
+        if mw % 64 or mh % 64:
+            continue
+        assert all(int(v) % 64 == 0 for v in c["out"]), c
+
+
+def test_native_unet_refuses_attention_mask_and_odd_grids():
+    """Accepted-and-ignored arguments are refused: `attention_mask` (threaded by the reference, models/unet_3d_condition.py:419-428;
+    no bias operand in the native attention core) and latent grids that would need the `upsample_size` path."""
+    import inspect
+    import t2v_amd.models.unet_3d_condition as m
+    src = inspect.getsource(m.UNet3DConditionModel.forward)
+    assert "attention_mask is not None" in src and "upsample_size" in src

@@ -202,11 +202,17 @@ def _full_case(config, scales):
     return out
 
 
+# one sketched tensor (>= 1 % of the gradient norm), relative error estimated from its 4 projections: a decorrelated (mis-laid-out)
+# tensor reads ~1.4; measured 0.13 - 0.27 over every full-size fixture of rounds 3 and 4 (profiles/r0*_parity.jsonl); the bar was
+# 0.5 in round 3 — a tensor 40 % off passed
+WORST_TENSOR_BAR = 0.35
+
+
 def _assert_case(row, bad_norm):
     fl_loss, fl_grad = row["floor_loss_rel"], row["floor_grad_rel"]
     assert row["loss_rel"] < max(1e-3, FLOOR_FACTOR * fl_loss), row       # north-star bar: 1e-3 (where the recipe itself meets it)
     assert row["grad_rel_sketch"] < FLOOR_FACTOR * max(fl_grad, 0.05), row
-    assert row["worst_tensor_rel_sketch"] < 0.5, row                       # a decorrelated (mis-laid-out) tensor reads ~1.4;
+    assert row["worst_tensor_rel_sketch"] < WORST_TENSOR_BAR, row                       # a decorrelated (mis-laid-out) tensor reads ~1.4;
                                                                            # measured 0.13 - 0.27 (profiles/r03_parity.jsonl)
     assert not bad_norm, bad_norm[:5]
     assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row
@@ -309,17 +315,19 @@ def test_toy_rank_beyond_the_merge_window_trains_and_matches_oracle():
     assert torch.isfinite(loss)
 
 
-def test_c3_full_finetune_gradients_match_the_oracle_fixture():
+@pytest.mark.parametrize("config", ["c3", "c3full"])
+def test_c3_full_finetune_gradients_match_the_oracle_fixture(config):
     """Config C3 (BASELINE.json configs[2], train.py:172-236: every UNet parameter trainable, no LoRA) at FULL model size: loss
     and the gradient of all 1.41 B parameters — complete +-1 sketch, per-tensor norms, exact samples — against the committed
-    CPU-oracle fixture (tests/golden/make_oracle_step.py --config c3; C1 clip).  The weight gradients come from the K-major
-    GEMM family (dW = x^T dy), which no LoRA configuration exercises at full size."""
+    CPU-oracle fixtures (tests/golden/make_oracle_step.py --config c3: the C1 clip; --config c3full: configs[2]'s own clip,
+    16 frames @256x256).  The weight gradients come from the K-major GEMM family (dW = x^T dy), which no LoRA configuration
+    exercises at full size."""
     from oracle.weights import synthetic_batch
     from t2v_amd.training import DenoiseTrainer
-    frames, H, W, _ = pu.CONFIGS["c3"]
+    frames, H, W, _ = pu.CONFIGS[config]
     ounet, ovae = pu.build_oracle_full_finetune(True)
-    fx = _load_fixture("c3", 0.0, ounet, ovae)
-    assert fx is not None, "tests/golden/oracle_step_c3_s0.pt is missing or was made for other weights"
+    fx = _load_fixture(config, 0.0, ounet, ovae)
+    assert fx is not None, f"tests/golden/oracle_step_{config}_s0.pt is missing or was made for other weights"
     dunet, dvae = pu.build_native_full_finetune(ounet, ovae)
     del ounet, ovae
     trainer = DenoiseTrainer(dunet, dvae, list(dunet.parameters()), lr=5e-6)
@@ -327,13 +335,13 @@ def test_c3_full_finetune_gradients_match_the_oracle_fixture():
     batch = synthetic_batch(frames, H, W, seed=1234)
     ld, gd = pu.native_loss_and_grads(trainer, dunet, batch)
     sk_rel, worst_big, bad_norm, c = _compare_with_fixture(fx, gd)
-    row = dict(test="full_c3", scale=0.0, loss_oracle=fx["loss"], loss_native=ld, loss_rel=abs(ld - fx["loss"]) / abs(fx["loss"]),
+    row = dict(test=f"full_{config}", scale=0.0, loss_oracle=fx["loss"], loss_native=ld, loss_rel=abs(ld - fx["loss"]) / abs(fx["loss"]),
                grad_rel_sketch=sk_rel, worst_tensor_rel_sketch=worst_big, norm_outliers=len(bad_norm), sample_rel=c["rel"],
                sample_cos=c["cos"], sample_worst_cos=c["worst_cos"], tensors=len(fx["sketches"]), fixture=True)
     _record(**row)
     print(row)
     assert row["loss_rel"] < 1e-3, row
-    assert row["grad_rel_sketch"] < 0.15 and row["worst_tensor_rel_sketch"] < 0.5, row
+    assert row["grad_rel_sketch"] < 0.15 and row["worst_tensor_rel_sketch"] < WORST_TENSOR_BAR, row
     assert not bad_norm, bad_norm[:5]
     assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row
 
@@ -371,6 +379,6 @@ def test_default_train_mode_with_dropout_matches_the_oracle_fixture(config):
     _record(**row)
     print(row)
     assert row["loss_rel"] < 1e-3, row                     # north_star's bar (a wrong or missing mask moves the loss by several 1e-2)
-    assert row["grad_rel_sketch"] < 0.15 and row["worst_tensor_rel_sketch"] < 0.5, row
+    assert row["grad_rel_sketch"] < 0.15 and row["worst_tensor_rel_sketch"] < WORST_TENSOR_BAR, row
     assert not bad_norm, bad_norm[:5]
     assert row["sample_cos"] > 0.97 and row["sample_worst_cos"] > 0.5, row
