@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 6   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
+#define T2V_ABI_VERSION 7   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -259,6 +259,7 @@ typedef struct {
   /* backward only */
   T2VAttnOperand d_o, dq, dk, dv;
   float* delta;   /* fp32 [nbatch, heads, Sq] workspace: rowsum(dO*O) */
+  int causal;     /* ABI v7: 1 = query i sees keys 0..i only (self-attention, Sq == Sk): the CLIP text tower of train.py:784-790 */
 } T2VAttn;
 int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream);
 int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream);
@@ -385,6 +386,17 @@ int t2v_lora_prep(const T2VLoraPrepJob* jobs_dev, int njobs, long long total_chu
 int t2v_geglu_fwd(const void* x, long long ldx, void* y, long long ldy, int rows, int inner, t2v_stream_t stream);
 int t2v_geglu_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int rows,
                   int inner, t2v_stream_t stream);
+/* y = gelu(x) on a flat bf16 array and its backward — the MLP activation of the CLIP text tower (train.py:784-790; kind 0: exact
+ * erf GELU, the ModelScope / OpenCLIP ViT-H text config; kind 1: quick_gelu x * sigmoid(1.702 x), OpenAI CLIP configs) */
+int t2v_gelu_fwd(const void* x, void* y, long long n, int kind, t2v_stream_t stream);
+int t2v_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int kind, t2v_stream_t stream);
+/* y[g, c] = sum over the `rows_per_group` consecutive rows of group g of x[., c]  (bf16 in, fp32 accumulate, bf16 out): the
+ * gradient of a per-video row-bias (time embedding) and of keys / values shared by the frames of a video */
+int t2v_rowgroup_sum(const void* x, long long ldx, void* y, long long ldy, int groups, int rows_per_group, int cols, float* workspace,
+                     t2v_stream_t stream);
+/* row splits the launch uses when `workspace` (caller-owned fp32 scratch of groups * t2v_rowgroup_splits() * cols elements, no
+ * initialisation needed) is given; NULL workspace: one workgroup column per group */
+int t2v_rowgroup_splits(int groups, int rows_per_group, int cols);
 /* y = silu(x) on a flat bf16 array (temb activation, ResnetBlock2D) and its backward */
 int t2v_silu_fwd(const void* x, void* y, long long n, t2v_stream_t stream);
 int t2v_silu_bwd(const void* x, const void* dy, void* dx, long long n, t2v_stream_t stream);

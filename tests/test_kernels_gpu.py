@@ -1185,3 +1185,18 @@ def test_groupnorm_fusion_end_to_end_matches_the_unfused_ops():
         del os.environ["T2V_GEMM_FORCE_CFG"]
     assert relerr(outs[0][0], outs[1][0]) < 5e-3
     assert relerr(outs[0][1], outs[1][1]) < 5e-3
+
+
+@pytest.mark.parametrize("groups,rpg,cols", [(2, 16384, 320), (2, 77, 1280), (32, 1024, 640), (1, 5, 8), (4, 4096, 1280)])
+def test_rowgroup_sum(groups, rpg, cols):
+    """t2v_rowgroup_sum: the gradient of a per-video row-bias (time embedding) / of keys and values shared by a video's frames —
+    fp32 accumulation in a fixed order (two launches of the same input give the same bits)."""
+    import t2v_amd.functional as F
+    g = torch.Generator().manual_seed(groups + rpg + cols)
+    x = _bf(torch.randn(groups * rpg, cols, generator=g))
+    ref = x.float().view(groups, rpg, cols).sum(1)
+    xd = x.cuda()
+    y1, y2 = F.rowgroup_sum(xd, groups, rpg), F.rowgroup_sum(xd, groups, rpg)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert relerr(y1, ref) < 5e-3

@@ -518,3 +518,44 @@ def test_reloaded_base_weights_reach_the_merged_path():
     print(f"loss before reload {l_old:.6f}; after: replay {l_new:.6f} eager {l_eager:.6f} fresh trainer {l_ref:.6f}")
     assert abs(l_old - l_ref) / l_ref > 1e-3                     # the perturbation matters
     assert abs(l_new - l_ref) / l_ref < 1e-4 and abs(l_eager - l_ref) / l_ref < 1e-4
+
+
+@pytest.mark.parametrize("act", ["gelu", "quick_gelu"])
+def test_native_clip_text_tower_matches_transformers(act):
+    """`text_encoder(token_ids)[0]` (train.py:784-790) through the native kernels — LayerNorm, q/k/v/out Linear,
+    CAUSAL self-attention (t2v_attn_fwd/bwd `causal`), fc1 -> GELU -> fc2, final LayerNorm — against the transformers module it
+    re-expresses, run in fp32 on the CPU with the same weights: hidden states, and the gradients of an fc weight, a q_proj weight
+    and a LayerNorm weight under a random cotangent."""
+    import copy
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from t2v_amd.models import clip_text
+    cfg = CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                         max_position_embeddings=77, hidden_act=act, projection_dim=128)
+    torch.manual_seed(4)
+    ref = CLIPTextModel(cfg).float().eval()
+    dut = copy.deepcopy(ref).cuda()
+    assert clip_text.supported(dut)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(0, 999, (2, 77), generator=g)
+    cot = torch.randn(2, 77, 128, generator=g)
+    yr = ref(ids)[0]
+    (yr * cot).sum().backward()
+    y = clip_text.text_states(dut, ids.cuda())
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16
+    (y.float() * cot.cuda()).sum().backward()
+    e = relerr(y.detach(), yr.detach())
+    print("native CLIP hidden states relerr", e)
+    assert e < 3e-2
+    # the causal mask matters: position 0 must not depend on later tokens
+    ids2 = ids.clone(); ids2[:, 5:] = (ids2[:, 5:] + 1) % 999
+    with torch.no_grad():
+        y2 = clip_text.text_states(dut, ids2.cuda())
+    assert torch.equal(y2[:, :5], y.detach()[:, :5]) and not torch.equal(y2[:, 5:], y.detach()[:, 5:])
+    rp, dp = dict(ref.named_parameters()), dict(dut.named_parameters())
+    names = [n for n in rp if n.endswith("layers.1.mlp.fc1.weight") or n.endswith("layers.0.self_attn.q_proj.weight")
+             or n.endswith("layers.2.layer_norm1.weight") or n.endswith("layers.1.self_attn.out_proj.bias")]
+    assert len(names) == 4
+    for n in names:
+        ge = relerr(dp[n].grad, rp[n].grad)
+        print(n, "grad relerr", ge)
+        assert ge < 6e-2, n

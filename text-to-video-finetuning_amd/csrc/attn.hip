@@ -118,7 +118,8 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const T2VAttn p) {
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float sv = (kt + crow(r, hi) < Sk) ? s[r] * p.scale : -INFINITY;
+      // (causal: CLIP's text tower — a query sees the keys up to its own position; key 0 is always visible, so m stays finite)
+      float sv = (kt + crow(r, hi) < Sk && (!p.causal || kt + crow(r, hi) <= q)) ? s[r] * p.scale : -INFINITY;
       s[r] = sv;
       mx = fmaxf(mx, sv);
     }
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const T2VAttn p) {
     for (int r = 0; r < 16; ++r) {
       float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
       if (ragged && kt + crow(r, hi) >= Sk) pv = 0.f;
+      if (p.causal && kt + crow(r, hi) > q) pv = 0.f;
       s[r] = pv * (dp[r] - dl) * p.scale;
     }
 #pragma unroll
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = qt + crow(r, hi);
-      const bool ok = (qr < Sq) && kok;
+      const bool ok = (qr < Sq) && kok && (!p.causal || key <= qr);
       const float L = ok ? lsep[qr] * 1.44269504088896341f : 0.f;
       const float D = ok ? dlp[qr] : 0.f;
       float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -L)) : 0.f;
@@ -1111,7 +1113,8 @@ extern "C" int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream) {
   if (int e = check_op("t2v_attn_fwd", "k", p->k)) return e;
   if (int e = check_op("t2v_attn_fwd", "v", p->v)) return e;
   if (int e = check_op("t2v_attn_fwd", "o", p->o)) return e;
-  if (const int P = packed_seqs(*p)) {
+  T2V_CHECK_ARG(!p->causal || p->Sq == p->Sk, "t2v_attn_fwd: the causal mask is defined for self-attention (Sq == Sk)");
+  if (const int P = p->causal ? 0 : packed_seqs(*p)) {
     T2V_CHECK_ARG(p->heads <= 65535, "t2v_attn_fwd: heads exceed grid limits (%d)", p->heads);
     T2V_LAUNCH(attn_fwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
                        p->Sq, P);
@@ -1121,7 +1124,7 @@ extern "C" int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream) {
   dim3 grid((p->Sq + 31) / 32, p->heads, p->nbatch);
   T2V_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "t2v_attn_fwd: heads/nbatch exceed grid limits (%d, %d)", p->heads,
                 p->nbatch);
-  if (use_wg(p->Sq)) {               // long query sequences: 4 waves share the K|V tiles through LDS
+  if (!p->causal && use_wg(p->Sq)) { // long query sequences: 4 waves share the K|V tiles through LDS (causal: one-wave kernels only)
     T2V_LAUNCH(attn_fwd_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
@@ -1138,7 +1141,8 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
   const char* names[] = {"q", "k", "v", "o", "d_o", "dq", "dk", "dv"};
   for (int i = 0; i < 8; ++i)
     if (int e = check_op("t2v_attn_bwd", names[i], *ops[i])) return e;
-  if (const int P = packed_seqs(*p)) {
+  T2V_CHECK_ARG(!p->causal || p->Sq == p->Sk, "t2v_attn_bwd: the causal mask is defined for self-attention (Sq == Sk)");
+  if (const int P = p->causal ? 0 : packed_seqs(*p)) {
     T2V_CHECK_ARG(p->heads <= 65535, "t2v_attn_bwd: heads exceed grid limits (%d)", p->heads);
     T2V_LAUNCH(attn_bwd_packed_kernel, dim3((p->nbatch + P - 1) / P, p->heads), dim3(64), 0, (hipStream_t)stream, *p,
                        p->Sq, P);
@@ -1147,17 +1151,17 @@ extern "C" int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream) {
   }
   T2V_CHECK_ARG(p->heads <= 65535 && p->nbatch <= 65535, "t2v_attn_bwd: heads/nbatch exceed grid limits");
   dim3 gq((p->Sq + 31) / 32, p->heads, p->nbatch);
-  if (use_wg2_bwd(p->Sq))
+  if (!p->causal && use_wg2_bwd(p->Sq))
     T2V_LAUNCH_FIRST(attn_bwd_dq_wg2_kernel, dim3((p->Sq + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
-  else if (use_wg_bwd(p->Sq))
+  else if (!p->causal && use_wg_bwd(p->Sq))
     T2V_LAUNCH_FIRST(attn_bwd_dq_wg_kernel, dim3((p->Sq + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
     T2V_LAUNCH_FIRST(attn_bwd_dq_kernel, gq, dim3(64), 0, (hipStream_t)stream, *p);
   T2V_CHECK_LAUNCH();
   dim3 gk((p->Sk + 31) / 32, p->heads, p->nbatch);
-  if (use_wg2_bwd(p->Sk))
+  if (!p->causal && use_wg2_bwd(p->Sk))
     T2V_LAUNCH_LAST(attn_bwd_dkdv_wg2_kernel, dim3((p->Sk + 255) / 256, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
-  else if (use_wg_bwd(p->Sk))
+  else if (!p->causal && use_wg_bwd(p->Sk))
     T2V_LAUNCH_LAST(attn_bwd_dkdv_wg_kernel, dim3((p->Sk + 127) / 128, p->heads, p->nbatch), dim3(256), 0, (hipStream_t)stream, *p);
   else
     T2V_LAUNCH_LAST(attn_bwd_dkdv_kernel, gk, dim3(64), 0, (hipStream_t)stream, *p);

@@ -469,6 +469,105 @@ __global__ void step_inc_kernel(int* step) { *step += 1; }
 
 }  // namespace
 
+
+// ---- GELU (CLIP text tower MLP): kind 0 exact erf, kind 1 quick_gelu
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long n8, int kind) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const bf16x8 v = *(const bf16x8*)(x + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = bf2f((unsigned short)v[e]);
+      o[e] = (short)f2bf(kind == 0 ? gelu_erf(f) : f * sigmoid_f(1.702f * f));
+    }
+    *(bf16x8*)(y + i * 8) = o;
+  }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                        long long n8, int kind) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const bf16x8 v = *(const bf16x8*)(x + i * 8), g = *(const bf16x8*)(dy + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = bf2f((unsigned short)v[e]);
+      float d;
+      if (kind == 0) {
+        d = gelu_erf_grad(f);
+      } else {
+        const float sg = sigmoid_f(1.702f * f);
+        d = sg * (1.f + 1.702f * f * (1.f - sg));
+      }
+      o[e] = (short)f2bf(bf2f((unsigned short)g[e]) * d);
+    }
+    *(bf16x8*)(dx + i * 8) = o;
+  }
+}
+// ---- sum over the consecutive rows of a group (fp32 accumulate, fixed order: bit-reproducible), two stages.  These reductions
+// have 2 .. 32 groups of 77 .. 16384 rows x 320 .. 1280 columns: a group alone gives a handful of workgroups, so stage 1 also splits
+// the rows (grid = column blocks x groups x row splits; a thread owns one 8-column chunk and walks its rows with four loads in
+// flight, the 8 row slices of a workgroup meet in LDS in slice order) and writes fp32 partials; stage 2 adds the splits in order.
+__global__ __launch_bounds__(256) void rowgroup_sum_kernel(const bf16_t* __restrict__ x, long long ldx, float* __restrict__ part,
+                                                            bf16_t* __restrict__ y, long long ldy, int rpg, int cols, int rsplit) {
+  __shared__ float red[256 * 8];
+  const int cpr = cols >> 3;
+  const int tid = threadIdx.x, cl = tid & 31, sl = tid >> 5;
+  const int cc = blockIdx.x * 32 + cl, g = blockIdx.y, z = blockIdx.z;
+  const int per = (rpg + rsplit - 1) / rsplit, r0 = z * per, r1 = min(rpg, r0 + per);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (cc < cpr) {
+    const bf16_t* xp = x + ((long long)g * rpg) * ldx + cc * 8;
+    for (int r = r0 + sl; r < r1; r += 8 * 4) {
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 8 * u < r1) v[u] = *(const bf16x8*)(xp + (long long)(r + 8 * u) * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 8 * u < r1)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += bf2f((unsigned short)v[u][e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[(sl * 32 + cl) * 8 + e] = acc[e];
+  __syncthreads();
+  if (sl == 0 && cc < cpr) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = 0.f;
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += red[(q * 32 + cl) * 8 + e];
+    if (rsplit == 1) {
+      *(bf16x8*)(y + (long long)g * ldy + cc * 8) = pack8bf(t);
+    } else {
+      float* pp = part + (((long long)g * rsplit + z) * cols + cc * 8);
+      *(float4*)pp = make_float4(t[0], t[1], t[2], t[3]);
+      *(float4*)(pp + 4) = make_float4(t[4], t[5], t[6], t[7]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void rowgroup_finish_kernel(const float* __restrict__ part, bf16_t* __restrict__ y, long long ldy, int groups,
+                                                               int cols, int rsplit) {
+  const int cpr = cols >> 3;
+  const long long n = (long long)groups * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i / cpr), cc = (int)(i - (long long)g * cpr);
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = 0.f;
+    for (int z = 0; z < rsplit; ++z) {
+      const float* pp = part + (((long long)g * rsplit + z) * cols + cc * 8);
+      const float4 a = *(const float4*)pp, b = *(const float4*)(pp + 4);
+      t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += b.x; t[5] += b.y; t[6] += b.z; t[7] += b.w;
+    }
+    *(bf16x8*)(y + (long long)g * ldy + cc * 8) = pack8bf(t);
+  }
+}
+
 #define LAUNCH1D(kern, n, s, ...)                                                           \
   hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__); \
   T2V_CHECK_LAUNCH();                                                                       \
@@ -638,5 +737,35 @@ extern "C" int t2v_adamw(float* p, const float* g, float* m, float* v, long long
   T2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step);
   T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
+extern "C" int t2v_gelu_fwd(const void* x, void* y, long long n, int kind, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && n > 0 && n % 8 == 0 && (kind == 0 || kind == 1), "t2v_gelu_fwd: bad args (n must be a multiple of 8)");
+  LAUNCH1D(gelu_fwd_kernel, n / 8, s, (const bf16_t*)x, (bf16_t*)y, n / 8, kind);
+}
+extern "C" int t2v_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int kind, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && dy && dx && n > 0 && n % 8 == 0 && (kind == 0 || kind == 1), "t2v_gelu_bwd: bad args (n must be a multiple of 8)");
+  LAUNCH1D(gelu_bwd_kernel, n / 8, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8, kind);
+}
+extern "C" int t2v_rowgroup_splits(int groups, int rows_per_group, int cols) {
+  // row splits so that the launch has ~512 workgroups, each with at least 64 rows
+  const long long base = (long long)((cols / 8 + 31) / 32) * groups;
+  long long sp = (512 + base - 1) / base;
+  if (sp > rows_per_group / 64) sp = rows_per_group / 64;
+  if (sp > 64) sp = 64;
+  return sp < 1 ? 1 : (int)sp;
+}
+extern "C" int t2v_rowgroup_sum(const void* x, long long ldx, void* y, long long ldy, int groups, int rows_per_group, int cols,
+                                float* workspace, t2v_stream_t s) {
+  T2V_CHECK_ARG(x && y && groups > 0 && groups <= 65535 && rows_per_group > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0,
+                "t2v_rowgroup_sum: bad args");
+  const int rsplit = workspace ? t2v_rowgroup_splits(groups, rows_per_group, cols) : 1;
+  hipLaunchKernelGGL(rowgroup_sum_kernel, dim3((cols / 8 + 31) / 32, groups, rsplit), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx,
+                     workspace, (bf16_t*)y, ldy, rows_per_group, cols, rsplit);
+  T2V_CHECK_LAUNCH();
+  if (rsplit > 1) {
+    LAUNCH1D(rowgroup_finish_kernel, (long long)groups * (cols / 8), s, (const float*)workspace, (bf16_t*)y, ldy, groups, cols, rsplit);
+  }
   return T2V_OK;
 }

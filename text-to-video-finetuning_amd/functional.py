@@ -123,6 +123,13 @@ def resync_prepared(params):
     since (load_state_dict / resume), re-derive its copies INTO THE SAME BUFFERS.  Returns the number of refreshed copies."""
     n = 0
     for w in params:
+        f32 = w.__dict__.get("_t2v_f32")          # cached fp32 copy of a frozen non-fp32 vector (functional._f32)
+        if f32 is not None:
+            tag = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+            if f32[0] != tag and f32[0][2] == tag[2]:
+                f32[1].copy_(w.detach().float())
+                w.__dict__["_t2v_f32"] = (tag, f32[1])
+                n += 1
         cache = w.__dict__.get("_t2v_prep")
         if not cache:
             continue
@@ -164,9 +171,21 @@ def prepared_weight(w, kind):
 
 
 def _f32(t):
+    """fp32 view / copy of a bias-like vector.  A FROZEN Parameter stored in another dtype (the bf16 CLIP text tower: 10 vectors per
+    layer) caches its copy on the Parameter object, validated like the prepared weights — a `.float()` per call was 233 cast
+    launches per step."""
     if t is None:
         return None
-    return t.detach() if t.dtype == torch.float32 else t.detach().float()
+    if t.dtype == torch.float32:
+        return t.detach()
+    if isinstance(t, torch.nn.Parameter) and not t.requires_grad:
+        tag = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+        hit = t.__dict__.get("_t2v_f32")
+        if hit is None or hit[0] != tag:
+            hit = (tag, t.detach().float())
+            t.__dict__["_t2v_f32"] = hit
+        return hit[1]
+    return t.detach().float()
 
 
 def _pad_vec(v, n):
@@ -247,7 +266,7 @@ def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0
         for i, sd in enumerate(lr.get("group_seeds", ())[:2]):
             g.lr_group_seed[i] = sd
     if use_ws and out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
-        ws = _gemm_workspace()          # one scratch per device: main-stream launches only (stream order serialises its users)
+        ws = _gemm_workspace()          # one scratch per (device, stream): stream order serialises its users
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     return g
 
@@ -256,13 +275,16 @@ _gemm_ws = {}
 
 
 def _gemm_workspace():
-    """fp32 scratch for library-side split-K (one per device; stream order serialises its users)."""
+    """fp32 scratch for library-side split-K: one per (device, stream) — stream order serialises the users of one buffer, and the
+    trainer runs GEMMs on two streams at once (the CLIP text tower and the parameter refresh beside the VAE encode)."""
     dev = torch.cuda.current_device()
-    buf = _gemm_ws.get(dev)
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    buf = _gemm_ws.get(key)
     if buf is None:
-        # 64 MB; zero-filled: its first 64 KB hold the arrival counters of the in-launch split-K reduction (t2v_abi.h), which
-        # every launch leaves zero
-        buf = _gemm_ws[dev] = torch.zeros(16 << 20, dtype=torch.float32, device=f"cuda:{dev}")
+        # 64 MB on the main stream, 16 MB on side streams; zero-filled: the first 64 KB hold the arrival counters of the in-launch
+        # split-K reduction (t2v_abi.h), which every launch leaves zero
+        n = (16 << 20) if not any(k[0] == dev for k in _gemm_ws) else (4 << 20)
+        buf = _gemm_ws[key] = torch.zeros(n, dtype=torch.float32, device=f"cuda:{dev}")
     return buf
 
 
@@ -324,7 +346,7 @@ class _ConvLinear(torch.autograd.Function):
         dres = dy if has_res else None
         drb = None
         if has_rb:
-            drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
+            drb = rowgroup_sum(dy, rowbias.shape[0], M // rowbias.shape[0])
         db = None
         if bias_grad:
             db = dy.sum(0, dtype=torch.float32)[: ctx.bias_n]
@@ -373,6 +395,18 @@ class _ConvLinear(torch.autograd.Function):
                         out_mode=nv.OUT_F32_ATOMIC, alpha=alpha, split_k=_split_k(tiles, M))
             dw = None if direct else _unprep_weight_grad(dwp, weight, cfg)
         return dx, dw, db, drb, dres, None, None, None, None, None, None
+
+
+def rowgroup_sum(x, groups, rows_per_group):
+    """[groups, cols] bf16 = sum over the `rows_per_group` consecutive rows of every group of x [groups * rows_per_group, cols]
+    (fp32 accumulation): the gradient of a per-video row-bias (time embedding) or of keys / values shared by a video's frames."""
+    x = _mat(x, "x")
+    cols = x.shape[1]
+    y = torch.empty(groups, cols, dtype=BF16, device=x.device)
+    sp = int(nv.lib().t2v_rowgroup_splits(groups, rows_per_group, cols))
+    ws = torch.empty(groups * sp * cols, dtype=torch.float32, device=x.device) if sp > 1 else None
+    nv.call("t2v_rowgroup_sum", x.data_ptr(), _ld(x), y.data_ptr(), cols, groups, rows_per_group, cols, nv.ptr(ws), nv.stream())
+    return y
 
 
 def launch_gemm_dropmask(dy, out, drop_p, drop_seed):
@@ -679,7 +713,7 @@ class _LoraLayer(torch.autograd.Function):
         dres = dy if has_res else None
         drb = None
         if has_rb:
-            drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
+            drb = rowgroup_sum(dy, rowbias.shape[0], M // rowbias.shape[0])
         cin_p = e.cin_p
         need_dx = ctx.needs_input_grad[0]
         # gradient of the LoRA branch output: g = mask dy / (1-p) with dropout on.  It is never materialised when the streaming
@@ -866,7 +900,7 @@ class _LoraMerged(torch.autograd.Function):
         dres = dy if has_res else None
         drb = None
         if has_rb:
-            drb = dy.view(rowbias.shape[0], M // rowbias.shape[0], npad).sum(1, dtype=torch.float32).to(BF16)
+            drb = rowgroup_sum(dy, rowbias.shape[0], M // rowbias.shape[0])
         dx, dt = None, None
         if ctx.needs_input_grad[0]:
             wb = e.weff_bwd                            # [Cin_p, taps*Np], flipped taps
@@ -1358,7 +1392,7 @@ def _operand(t, lay):
 
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, heads, qlay, klay, scale):
+    def forward(ctx, q, k, v, heads, qlay, klay, scale, causal=False):
         q, k, v = _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
         o = torch.empty(q.shape[0], heads * 64, dtype=BF16, device=q.device)
         lse = torch.empty(qlay.nbatch * heads * qlay.S, dtype=torch.float32, device=q.device)
@@ -1366,15 +1400,16 @@ class _Attention(torch.autograd.Function):
         a.nbatch, a.heads, a.Sq, a.Sk, a.scale = qlay.nbatch, heads, qlay.S, klay.S, scale
         a.q, a.k, a.v, a.o = _operand(q, qlay), _operand(k, klay), _operand(v, klay), _operand(o, qlay)
         a.lse = lse.data_ptr()
+        a.causal = int(causal)
         nv.call("t2v_attn_fwd", C.byref(a), nv.stream())
-        ctx.meta = (heads, qlay, klay, scale)
+        ctx.meta = (heads, qlay, klay, scale, int(causal))
         ctx.save_for_backward(q, k, v, o, lse)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        heads, qlay, klay, scale = ctx.meta
+        heads, qlay, klay, scale, causal = ctx.meta
         do = _mat(do if do.stride(1) == 1 else do.contiguous(), "do")
         width = heads * 64
         fused_qkv = _adjacent_columns((q, k, v))
@@ -1405,17 +1440,20 @@ class _Attention(torch.autograd.Function):
         a.lse = lse.data_ptr()
         a.d_o, a.dq, a.dk, a.dv = _operand(do, qlay), _operand(dq, qlay), _operand(dk, dklay), _operand(dv, dklay)
         a.delta = delta.data_ptr()
+        a.causal = causal
         nv.call("t2v_attn_bwd", C.byref(a), nv.stream())
         if shared:
             nb_kv = qlay.nbatch // klay.bdiv
-            dk = dk.view(nb_kv, klay.bdiv, klay.S * width).sum(1, dtype=torch.float32).to(BF16).view(nb_kv * klay.S, width)
-            dv = dv.view(nb_kv, klay.bdiv, klay.S * width).sum(1, dtype=torch.float32).to(BF16).view(nb_kv * klay.S, width)
-        return dq, dk, dv, None, None, None, None
+            # (sum over the frames that share one K / V: [nb_kv, bdiv, S*width] -> [nb_kv, S*width])
+            dk = rowgroup_sum(dk.view(nb_kv * klay.bdiv, klay.S * width), nb_kv, klay.bdiv).view(nb_kv * klay.S, width)
+            dv = rowgroup_sum(dv.view(nb_kv * klay.bdiv, klay.S * width), nb_kv, klay.bdiv).view(nb_kv * klay.S, width)
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, heads, qlay, klay, scale=0.125):
-    """q: [rows_q, heads*64]; k, v: [rows_kv, heads*64] (must be dense row-major); layouts describe batching."""
-    return _Attention.apply(q, k, v, int(heads), qlay, klay, float(scale))
+def attention(q, k, v, heads, qlay, klay, scale=0.125, causal=False):
+    """q: [rows_q, heads*64]; k, v: [rows_kv, heads*64] (must be dense row-major); layouts describe batching.  `causal`: query i
+    attends to keys 0..i (self-attention of the CLIP text tower)."""
+    return _Attention.apply(q, k, v, int(heads), qlay, klay, float(scale), bool(causal))
 
 
 # --------------------------------------------------------------------------- GEGLU / SiLU
@@ -1462,6 +1500,34 @@ class _Silu(torch.autograd.Function):
         dx = torch.empty_like(x)
         nv.call("t2v_silu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), nv.stream())
         return dx
+
+
+class _Gelu(torch.autograd.Function):
+    """GELU on a bf16 tensor: kind 0 exact erf (`gelu`), 1 `quick_gelu` — the MLP activation of the CLIP text tower."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        nv.require_cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        nv.call("t2v_gelu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), kind, nv.stream())
+        ctx.kind = kind
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        nv.call("t2v_gelu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), ctx.kind, nv.stream())
+        return dx, None
+
+
+def gelu(x, kind=0):
+    if x.dtype != BF16 or x.numel() % 8:
+        raise RuntimeError("t2v_amd: gelu expects a bf16 tensor whose size is a multiple of 8")
+    return _Gelu.apply(x, int(kind))
 
 
 def silu(x):

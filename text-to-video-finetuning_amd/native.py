@@ -97,11 +97,11 @@ class Attn(C.Structure):
         ("q", AttnOperand), ("k", AttnOperand), ("v", AttnOperand), ("o", AttnOperand),
         ("lse", c_void_p),
         ("d_o", AttnOperand), ("dq", AttnOperand), ("dk", AttnOperand), ("dv", AttnOperand),
-        ("delta", c_void_p),
+        ("delta", c_void_p), ("causal", c_int),
     ]
 
 
-ABI_VERSION = 6          # include/t2v_abi.h T2V_ABI_VERSION
+ABI_VERSION = 7          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
@@ -137,6 +137,10 @@ SYMBOLS = {
                           c_int),
     "t2v_layernorm_bwd": ([c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_ll, c_void_p], c_int),
+    "t2v_gelu_fwd": ([c_void_p, c_void_p, c_ll, c_int, c_void_p], c_int),
+    "t2v_gelu_bwd": ([c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p], c_int),
+    "t2v_rowgroup_sum": ([c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "t2v_rowgroup_splits": ([c_int, c_int, c_int], c_int),
     "t2v_attn_fwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_attn_bwd": ([C.POINTER(Attn), c_void_p], c_int),
     "t2v_softmax_rows": ([c_void_p, c_ll, c_void_p, c_ll, c_ll, c_int, c_void_p], c_int),

@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import native as nv
+from .models.clip_text import encode as encode_text
 from .models.vae import tensor_to_vae_latent
 from .schedulers import DDPMScheduler
 
@@ -245,7 +246,7 @@ class DenoiseTrainer:
                  offset_noise_strength=0.1, rescale_schedule=False, cache_latents=False, gradient_accumulation_steps=1,
                  lr_scheduler="constant", lr_warmup_steps=0, max_train_steps=None):
         self.unet, self.vae = unet, vae
-        self.text_encoder = text_encoder           # frozen CLIPTextModel (train.py:784-790); runs through stock torch ops
+        self.text_encoder = text_encoder           # CLIPTextModel (train.py:784-790): native forward (models/clip_text.py)
         self._aux_stream = None
         self.batch_passes = True                   # evaluate the two UNet passes of train.py:814 as one stacked forward
         self.use_offset_noise = use_offset_noise and not rescale_schedule      # train.py:750
@@ -274,7 +275,7 @@ class DenoiseTrainer:
         text_trainable = self.text_encoder is not None and any(p.requires_grad for p in self.text_encoder.parameters())
         if text_trainable:                           # train.py:763-790: text encoder in the autograd graph (main stream)
             ids = batch["prompt_ids"]
-            ehs = self.text_encoder(ids[0] if ids.dim() > 2 else ids)[0]
+            ehs = encode_text(self.text_encoder, ids[0] if ids.dim() > 2 else ids)
         elif "encoder_hidden_states" not in batch:   # train.py:784-790: frozen text encoder (no grad) — independent of the
             ids = batch["prompt_ids"]                # VAE encode, so it runs on an auxiliary stream beside it
             if ids.dim() > 2:
@@ -282,7 +283,7 @@ class DenoiseTrainer:
             aux = self._aux()
             aux.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(aux), torch.no_grad():
-                ehs = self.text_encoder(ids)[0]
+                ehs = encode_text(self.text_encoder, ids)
         if "latents" in batch or self.cache_latents:     # cache_latents path (train.py:741-746)
             latents = batch["latents"] if "latents" in batch else batch["pixel_values"]
         else:
