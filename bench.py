@@ -222,7 +222,7 @@ def gemm_roofline(trainer, batch):
         if nn_kernel and geom is not None and geom.KH == 3 and geom.KW == 1:
             # the (3,1,1) Conv3d launches (forward + backward-data): SURVEY 8(d) bytes = x once + y once + weights once
             taps = 3
-            conv3d.append((flops, (kw["M"] * (kw["K"] // taps) + kw["M"] * kw["N"] + kw["N"] * kw["K"]) * 2.0, s, e, inner))
+            conv3d.append((flops, (kw["M"] * (kw["K"] // taps) + kw["M"] * kw["N"] + kw["N"] * kw["K"]) * 2.0, s, e, inner, kw["M"]))
         return ret
 
     orig_pair = F.launch_gemm_pair
@@ -356,6 +356,13 @@ def gemm_roofline(trainer, batch):
     if conv3d:
         ns["conv3d_3x1x1"] = both_roofs(sum(c[0] for c in conv3d), sum(c[1] for c in conv3d),
                                         sum(dur(c[2], c[3], c[4]) for c in conv3d), len(conv3d))
+        # the weight-streaming end of the same family (the only launches where "Conv3d against the HBM roof" is
+        # coherent — M <= 512 rows, 3 C^2 weights dominate the bytes)
+        small = [c for c in conv3d if c[5] <= 512]
+        if small:
+            ns["conv3d_3x1x1_small_M"] = both_roofs(sum(c[0] for c in small), sum(c[1] for c in small),
+                                                    sum(dur(c[2], c[3], c[4]) for c in small), len(small))
+            ns["conv3d_3x1x1_small_M"]["rows"] = sorted({int(c[5]) for c in small})
     if wgrad:
         ns["lora_factor_gradients"] = both_roofs(sum(c[0] for c in wgrad), sum(c[1] for c in wgrad),
                                                  sum(dur(c[2], c[3], c[4]) for c in wgrad), len(wgrad))
@@ -643,6 +650,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     final_loss = float(loss.item())
+    trainer.check_device_flags()        # a split-K hand-off that gave up inside the timed region voids the line: fail loudly
 
     default_mode_ms = None
     if (rank == 0 and world == 1 and args.config == "c2" and not args.no_default_mode and use_graph):

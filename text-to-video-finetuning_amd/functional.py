@@ -288,6 +288,21 @@ def _gemm_workspace():
     return buf
 
 
+def check_gemm_workspaces():
+    """Host-side read of the split-K give-up flag (gemm_w8.hip: a reducer that times out waiting for its writers stores 0xdead in
+    word 16383 of the workspace and sums incomplete slabs).  Synchronises; raises if any workspace carries the flag and re-zeroes
+    the 64 KB of arrival counters so that later launches start from a clean state.  Meant for validation loops and the end of a
+    training run (`DenoiseTrainer.check_device_flags`), not for the inside of a step."""
+    bad = []
+    for key, buf in _gemm_ws.items():
+        if int(buf[16383:16384].view(torch.int32).item()) == 0xdead:
+            bad.append(key)
+            buf[:16384].zero_()
+    if bad:
+        raise RuntimeError(f"t2v_gemm: an in-launch split-K reduction timed out on (device, stream) {bad}: the results of that "
+                           "step are wrong; the arrival counters have been re-armed")
+
+
 def _split_k(tiles, kdim):
     """K splits of a K-major launch with `tiles` 64x64 output tiles: about 1600 workgroups (measured optimum of the weight-
     gradient signatures at 320^2 .. 1280^2 outputs, scripts/kmajor_probe.py), at least 128 reduction rows per split."""

@@ -400,6 +400,12 @@ class DenoiseTrainer:
     def train_step(self, batch):
         return self._micro_step(lambda: self._fwd_bwd(batch))
 
+    @staticmethod
+    def check_device_flags():
+        """Raise if a kernel of an earlier step flagged a device-side failure (split-K hand-off time-out).  Synchronises."""
+        from .functional import check_gemm_workspaces
+        check_gemm_workspaces()
+
     # ---- HIP-graph replay of forward+backward (static shapes)
     def capture(self, batch, warmup=2):
         # Active dropout is captured too: the seeds frozen into the graph are offset per replay by the device-side dropout
