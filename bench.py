@@ -609,7 +609,7 @@ def main():
             ids = batch.pop("prompt_ids")
             with torch.no_grad():
                 batch["encoder_hidden_states"] = text_encoder(ids[0])[0]
-            trainer.capture(batch, warmup=1)
+            trainer.capture(batch, warmup=1, pipelined=False)
             _replay = trainer.replay_step
 
             def step():
@@ -722,6 +722,7 @@ def main():
                                    + (", gradient checkpointing on" if args.grad_checkpointing else "")
                                    + f", text encoder: {text_mode}",
                        "global_batch": world, "parallelism": f"dp{world}", "graph_replay": use_graph,
+                       "graph_pipeline": bool(use_graph and getattr(trainer, "_pipe", None) is not None),
                        "trainable_params": sum(p.numel() for p in trainer.opt.params),
                        "flat_gradient_elems": trainer.opt.numel, "final_loss": final_loss,
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),

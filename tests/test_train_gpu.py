@@ -135,9 +135,13 @@ def test_lora_train_steps_match_oracle():
     assert float(upd_o.norm()) > 0 and cos > 0.85
 
 
-def test_graph_replay_equals_eager():
+@pytest.mark.parametrize("mode", ["pipelined", "one_graph", "forked"])
+def test_graph_replay_equals_eager(mode, monkeypatch):
     """HIP-graph replay of forward+backward must reproduce the eager step: identical loss at identical parameters
-    (step 0, up to the fp32 atomics of the loss/weight-gradient reductions) and the same short trajectory."""
+    (step 0, up to the fp32 atomics of the loss/weight-gradient reductions) and the same short trajectory — in every capture form
+    (DenoiseTrainer.capture: prepare / UNet graph pairs on two streams, one single-stream graph, round 3's forked graph)."""
+    if mode == "forked":
+        monkeypatch.setenv("T2V_GRAPH_FORK", "1")
     from oracle.weights import synthetic_batch
     from t2v_amd.training import DenoiseTrainer
     _, _, dunet, dvae, _ = _build(r=4)
@@ -147,8 +151,9 @@ def test_graph_replay_equals_eager():
     batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=7, text_dim=64).items()}
     t1 = DenoiseTrainer(dunet, dvae, p1, lr=1e-4)
     t2 = DenoiseTrainer(dunet2, dvae, p2, lr=1e-4)
-    t2.capture(batch, warmup=1)
-    for i in range(3):
+    t2.capture(batch, warmup=1, pipelined=(mode == "pipelined"))
+    assert (t2._pipe is not None) == (mode == "pipelined")
+    for i in range(4 if mode == "pipelined" else 3):          # (pipelined: both slots twice)
         l1 = t1.train_step(batch)
         l2 = t2.replay_step(batch)
         torch.cuda.synchronize()
@@ -158,6 +163,36 @@ def test_graph_replay_equals_eager():
         assert rel < (1e-5 if i == 0 else 5e-3)      # later steps: AdamW's sign-like first updates amplify 1-ulp differences
     assert relerr(t2.opt.flat_p, t1.opt.flat_p) < 1e-2
     t2.check_device_flags()          # no in-launch split-K reduction gave up (the 0xdead word is read by the host)
+
+
+@pytest.mark.parametrize("host_batches", [False, True])
+def test_pipelined_replays_without_host_sync_follow_the_eager_trajectory(host_batches):
+    """The pipelined capture form with the host running ahead: six replays on six DIFFERENT batches, no synchronisation in
+    between (prepare graph of step i+1 on the auxiliary stream beside the UNet graph of step i, slots reused every other step),
+    device batches and pinned host batches (uploaded on the auxiliary stream) — every step's loss must equal the eager trainer's
+    on the same batch sequence."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4)
+    dunet2 = copy.deepcopy(dunet)
+    t1 = DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=1e-4)
+    t2 = DenoiseTrainer(dunet2, dvae, [p for p in dunet2.parameters() if p.requires_grad], lr=1e-4)
+    cpu = [synthetic_batch(4, 64, 64, seed=100 + i, text_dim=64) for i in range(6)]
+    dev = [{k: v.cuda() for k, v in b.items()} for b in cpu]
+    if host_batches:
+        cpu = [{k: v.pin_memory() for k, v in b.items()} for b in cpu]
+    t2.capture(dev[0], warmup=1, pipelined=True)
+    torch.cuda.synchronize()
+    got = [t2.replay_step((cpu if host_batches else dev)[i]).clone() for i in range(6)]      # no host sync inside
+    torch.cuda.synchronize()
+    want = [t1.train_step(dev[i]).clone() for i in range(6)]
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        rel = abs(a.item() - b.item()) / abs(b.item())
+        print(f"step {i}: replay {a.item():.6f} eager {b.item():.6f} rel {rel:.2e}")
+        assert rel < (1e-5 if i == 0 else 5e-3)
+    assert len({round(v.item(), 5) for v in want}) == 6          # the batches really differ
+    assert relerr(t2.opt.flat_p, t1.opt.flat_p) < 1e-2
 
 
 def test_cached_latents_path_equals_encode_path():

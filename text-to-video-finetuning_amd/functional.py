@@ -281,10 +281,9 @@ def _gemm_workspace():
     key = (dev, torch.cuda.current_stream().cuda_stream)
     buf = _gemm_ws.get(key)
     if buf is None:
-        # 64 MB on the main stream, 16 MB on side streams; zero-filled: the first 64 KB hold the arrival counters of the in-launch
-        # split-K reduction (t2v_abi.h), which every launch leaves zero
-        n = (16 << 20) if not any(k[0] == dev for k in _gemm_ws) else (4 << 20)
-        buf = _gemm_ws[key] = torch.zeros(n, dtype=torch.float32, device=f"cuda:{dev}")
+        # 64 MB per launch stream (288 GB of HBM: the trainer's three streams hold 192 MB); zero-filled: the first 64 KB hold the
+        # arrival counters of the in-launch split-K reduction (t2v_abi.h), which every launch leaves zero
+        buf = _gemm_ws[key] = torch.zeros(16 << 20, dtype=torch.float32, device=f"cuda:{dev}")
     return buf
 
 
@@ -1253,12 +1252,14 @@ _gn_ws = {}
 
 
 def _gn_workspace(ndomains, G, device):
-    """Scratch for the fixed-order statistics reduction; one buffer per device, reused by every call on the stream
-    (stream order serialises the stats -> finalize pairs that use it)."""
+    """Scratch for the fixed-order statistics reduction; one buffer per (device, stream), reused by every call on that stream
+    (stream order serialises the stats -> finalize pairs that use it; the VAE encode of the NEXT step runs on the trainer's
+    auxiliary stream beside the UNet's norms)."""
     need = int(nv.lib().t2v_gn_workspace_floats(ndomains, G))
-    buf = _gn_ws.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _gn_ws.get(key)
     if buf is None or buf.numel() < need:
-        buf = _gn_ws[device] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=device)
+        buf = _gn_ws[key] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=device)
     return buf
 
 

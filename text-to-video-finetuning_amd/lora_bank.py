@@ -281,19 +281,40 @@ class MergePlan:
             self._base_tags.append(self._tag(base.weight))
         self.njobs = len(entries)
         self.ntiles = 0
+        self._jobs = jobs
+        self._tables = {}        # subset of entries (tuple of indices, None = all) -> (jobs_dev, tile_job_dev, njobs, ntiles)
         if self.njobs:
-            lib = nv.lib()
-            total = lib.t2v_lora_merge_plan(jobs, self.njobs, None, 0)
-            if total <= 0:
-                nv.check(int(total) if total < 0 else -1, "t2v_lora_merge_plan")
-            tile_job = (C.c_int * total)()
-            total2 = lib.t2v_lora_merge_plan(jobs, self.njobs, tile_job, total)
-            if total2 != total:
-                nv.check(-1, "t2v_lora_merge_plan")
-            self.ntiles = int(total)
-            self.jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
-            self.tile_job_dev = torch.frombuffer(bytearray(bytes(tile_job)), dtype=torch.int32).to(dev)
+            self.jobs_dev, self.tile_job_dev, _, self.ntiles = self._table(None)
         self.bytes = sum(w.numel() * 4 for w in self._keep) + sum(e.weff_fwd.numel() * 4 for e, _ in entries)
+
+    def _table(self, subset):
+        """Device job table + tile list of the entries `subset` (tuple of indices; None = every entry), built once per subset."""
+        tab = self._tables.get(subset)
+        if tab is not None:
+            return tab
+        import ctypes as C
+
+        from . import native as nv
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("t2v_amd: the LoRA merge table for this set of dropping wrappers has not been built yet; run one "
+                               "eager step in this mode before capturing (DenoiseTrainer.capture does)")
+        idx = range(self.njobs) if subset is None else subset
+        jobs = (nv.LoraMergeJob * max(1, len(idx)))()
+        for q, k in enumerate(idx):
+            C.memmove(C.byref(jobs[q]), C.byref(self._jobs[k]), C.sizeof(nv.LoraMergeJob))
+        lib = nv.lib()
+        n = len(idx)
+        total = lib.t2v_lora_merge_plan(jobs, n, None, 0)
+        if total <= 0:
+            nv.check(int(total) if total < 0 else -1, "t2v_lora_merge_plan")
+        tile_job = (C.c_int * total)()
+        if lib.t2v_lora_merge_plan(jobs, n, tile_job, total) != total:
+            nv.check(-1, "t2v_lora_merge_plan")
+        dev = self._keep[0].device
+        tab = (torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev),
+               torch.frombuffer(bytearray(bytes(tile_job)), dtype=torch.int32).to(dev), n, int(total))
+        self._tables[subset] = tab
+        return tab
 
     @staticmethod
     def _tag(w):
@@ -319,42 +340,60 @@ class MergePlan:
                                    f"({e.merge_scale} -> {float(mod.scale)}); rebuild the optimiser / trainer")
         return n
 
+    @staticmethod
+    def _drops(mod):
+        d = getattr(mod, "dropout", None)
+        return isinstance(d, torch.nn.Dropout) and d.training and d.p > 0.0
+
     def wanted(self):
-        """True if some wrapped layer can take the merged path right now: wrappers whose dropout is active (the reference's
-        default train mode, utils/lora.py:35,89) evaluate the branch apart and never read W_eff — refreshing it would be 15 GB
-        of HBM traffic per step for nothing."""
-        for _, mod in self.entries:
-            d = getattr(mod, "dropout", None)
-            if not (isinstance(d, torch.nn.Dropout) and d.training and d.p > 0.0):
-                return True
-        return False
+        """Indices of the entries whose wrapper can take the merged path right now: wrappers whose dropout is active (the
+        reference's default train mode, utils/lora.py:35,89) evaluate the branch apart and never read W_eff — refreshing theirs
+        is HBM traffic for nothing (all 574 layers: 15 GB per step; in the default mode only the Conv3d wrappers, whose
+        dropout_p is 0, stay merged).  A projection group is refreshed as a whole or not at all."""
+        ok = [not self._drops(mod) for _, mod in self.entries]
+        if not all(ok):
+            if getattr(self, "_members", None) is None:
+                self._members = {}
+                for k, (e, _) in enumerate(self.entries):
+                    if e.group is not None:
+                        self._members.setdefault(id(e.group), []).append(k)
+            for idx in self._members.values():
+                if not all(ok[k] for k in idx):
+                    for k in idx:
+                        ok[k] = False
+        return tuple(k for k, v in enumerate(ok) if v)
 
     def _mark(self, current):
-        """W_eff valid / stale: a stale merged weight switches the layers to the branch-apart path (leaves.run_layer compares
-        `merge_scale` with the wrapper's scale), so skipping a refresh can never feed stale weights to a forward."""
+        """W_eff valid / stale per entry (`current`: tuple of entry indices): a stale merged weight switches the layer to the
+        branch-apart path (leaves.run_layer compares `merge_scale` with the wrapper's scale), so skipping a refresh can never
+        feed stale weights to a forward."""
         if current == getattr(self, "_current", None):
             return
         self._current = current
+        cur = set(current)
         groups = {}
-        for e, mod in self.entries:
-            e.merge_scale = float(mod.scale) if current else None
+        for k, (e, mod) in enumerate(self.entries):
+            e.merge_scale = float(mod.scale) if k in cur else None
             if e.group is not None:
-                groups[id(e.group)] = e.group
-        for g in groups.values():
-            g.merge_scale = float(g.mods[0].scale) if current else None
+                groups[id(e.group)] = (e.group, k in cur)
+        for g, on in groups.values():
+            g.merge_scale = float(g.mods[0].scale) if on else None
 
     def run(self):
-        """Refresh every W_eff from the current fp32 factors (asynchronous on the current stream; graph-capture safe)."""
+        """Refresh the W_eff that are read this step from the current fp32 factors (asynchronous on the current stream;
+        graph-capture safe once the subset's table exists)."""
         if not self.njobs:
             return
         if not torch.cuda.is_current_stream_capturing():
             self.sync_base()
-        if not self.wanted():
-            self._mark(False)
+        want = self.wanted()
+        if not want:
+            self._mark(())
             return
-        self._mark(True)
+        jobs_dev, tile_job_dev, n, ntiles = self._table(None if len(want) == self.njobs else want)
+        self._mark(want)
         from . import native as nv
-        nv.call("t2v_lora_merge", self.jobs_dev.data_ptr(), self.njobs, self.tile_job_dev.data_ptr(), self.ntiles, nv.stream())
+        nv.call("t2v_lora_merge", jobs_dev.data_ptr(), n, tile_job_dev.data_ptr(), ntiles, nv.stream())
 
 
 class PrepPlan:

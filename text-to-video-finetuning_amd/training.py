@@ -268,22 +268,34 @@ class DenoiseTrainer:
         self._drop_epoch = None                    # device-side dropout epoch (ranks start 2^32 apart: different masks per rank)
         self._graph = None
         self._static = None
+        self._pipe = None
+        self._cap_stream = None
+        self._inline_aux = False
 
     # ---- train.py:720-836
-    def loss_fn(self, batch):
-        ehs, aux = None, None
-        text_trainable = self.text_encoder is not None and any(p.requires_grad for p in self.text_encoder.parameters())
-        if text_trainable:                           # train.py:763-790: text encoder in the autograd graph (main stream)
-            ids = batch["prompt_ids"]
-            ehs = encode_text(self.text_encoder, ids[0] if ids.dim() > 2 else ids)
-        elif "encoder_hidden_states" not in batch:   # train.py:784-790: frozen text encoder (no grad) — independent of the
-            ids = batch["prompt_ids"]                # VAE encode, so it runs on an auxiliary stream beside it
-            if ids.dim() > 2:
-                ids = ids[0]
-            aux = self._aux()
-            aux.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(aux), torch.no_grad():
-                ehs = encode_text(self.text_encoder, ids)
+    def _text_trainable(self):
+        return self.text_encoder is not None and any(p.requires_grad for p in self.text_encoder.parameters())
+
+    def _prepare(self, batch, side_clip=True):
+        """The part of a step that does not depend on the trainable parameters (train.py:720-800): frozen text encoder, VAE
+        encode, noise, timesteps, add_noise.  -> dict(noisy, target, timesteps, ehs, ids).  `side_clip`: run the frozen CLIP
+        tower on the auxiliary stream beside the VAE encode (joined by `_unet_loss`); False = everything on the current stream
+        (the pipelined capture records this whole part as ONE single-stream graph that runs on the auxiliary stream)."""
+        ehs, ids = batch.get("encoder_hidden_states"), batch.get("prompt_ids")
+        if ids is not None and ids.dim() > 2:
+            ids = ids[0]
+        if self._text_trainable():
+            ehs = None                                   # (train.py:763-790: encoded inside the autograd graph, `_unet_loss`)
+        elif ehs is None:
+            # train.py:784-790: frozen text encoder (no grad) — independent of the VAE encode
+            if side_clip:
+                aux = self._aux()
+                aux.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(aux), torch.no_grad():
+                    ehs = encode_text(self.text_encoder, ids)
+            else:
+                with torch.no_grad():
+                    ehs = encode_text(self.text_encoder, ids)
         if "latents" in batch or self.cache_latents:     # cache_latents path (train.py:741-746)
             latents = batch["latents"] if "latents" in batch else batch["pixel_values"]
         else:
@@ -295,17 +307,24 @@ class DenoiseTrainer:
         else:
             timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bsz,), device=latents.device).long()
         noisy = self.scheduler.add_noise(latents, noise, timesteps)
-        if self._aux_stream is not None:             # CLIP and/or the parameter refresh of _fwd_bwd ran beside the VAE encode
-            torch.cuda.current_stream().wait_stream(self._aux_stream)
-        if ehs is None:
-            ehs = batch["encoder_hidden_states"]
         if self.scheduler.prediction_type == "epsilon":
             target = noise
         elif self.scheduler.prediction_type == "v_prediction":
             target = self.scheduler.get_velocity(latents, noise, timesteps)
         else:
             raise ValueError(f"Unknown prediction type {self.scheduler.prediction_type}")
-        video_length = latents.shape[2]
+        return {"noisy": noisy, "target": target, "timesteps": timesteps, "ehs": ehs, "ids": ids}
+
+    def _unet_loss(self, prep, join_aux=True):
+        """train.py:800-836: the UNet passes and the eps-MSE on a prepared batch."""
+        noisy, target, timesteps, ehs = prep["noisy"], prep["target"], prep["timesteps"], prep["ehs"]
+        bsz = noisy.shape[0]
+        text_trainable = self._text_trainable()
+        if text_trainable and ehs is None:           # train.py:763-790: text encoder in the autograd graph (main stream)
+            ehs = encode_text(self.text_encoder, prep["ids"])
+        if join_aux and not self._inline_aux and self._aux_stream is not None:  # CLIP and/or the parameter refresh of _fwd_bwd ran beside the VAE encode
+            torch.cuda.current_stream().wait_stream(self._aux_stream)
+        video_length = noisy.shape[2]
         if text_trainable and video_length > 1:
             # train.py:805-828: pass 0 = whole clip with DETACHED text states; pass 1 = frame 1 only with the trainable
             # states ("train text information only on the spatial layers")
@@ -328,6 +347,9 @@ class DenoiseTrainer:
                 break
         return losses[0] if len(losses) == 1 else losses[0] + losses[1]
 
+    def loss_fn(self, batch):
+        return self._unet_loss(self._prepare(batch))
+
     def sample_noise(self, latents):
         """train.py:349-358: eps ~ N(0,1), optionally plus a per-(b,c,f) offset."""
         noise = torch.randn_like(latents)
@@ -337,11 +359,15 @@ class DenoiseTrainer:
         return noise
 
     def _aux(self):
+        if self._inline_aux:                       # single-stream capture: the "auxiliary" work stays on the launch stream
+            return torch.cuda.current_stream()
         if self._aux_stream is None:
             self._aux_stream = torch.cuda.Stream()
         return self._aux_stream
 
-    def _fwd_bwd(self, batch):
+    def _fwd_bwd(self, batch, prep=None):
+        """Forward + backward of one step.  `prep`: the output of `_prepare` when that part has already run (pipelined replay:
+        on the auxiliary stream, as its own graph) — then everything here stays on the current stream."""
         # Dropout epoch: seeds reach the kernels by value (host counter, models/leaves.py::_next_seed), which a captured graph
         # would freeze; the launches of this step therefore also carry the address of a device counter that the step bumps
         # first thing (one captured add), so every replay draws fresh masks while forward and backward of a step agree.
@@ -350,13 +376,17 @@ class DenoiseTrainer:
         self._drop_epoch += 1
         nv.call("t2v_set_dropout_epoch", self._drop_epoch.data_ptr())
         try:
-            # bf16 factor copies + merged weights W_eff for this step (one cast + one merge kernel, HBM-bound): on the
-            # auxiliary stream, beside the MFMA-bound VAE encode; loss_fn joins it before the UNet
-            aux = self._aux()
-            aux.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(aux):
+            if prep is None:
+                # bf16 factor copies + merged weights W_eff for this step (one cast + one merge kernel, HBM-bound): on the
+                # auxiliary stream, beside the MFMA-bound VAE encode; `_unet_loss` joins it before the UNet
+                aux = self._aux()
+                aux.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(aux):
+                    self.opt.refresh_bf16()
+                loss = self.loss_fn(batch)
+            else:
                 self.opt.refresh_bf16()
-            loss = self.loss_fn(batch)
+                loss = self._unet_loss(prep, join_aux=False)
             loss.backward()
             from .functional import join_side_stream
             join_side_stream()             # the last factor-gradient batch is enqueued before clip / AdamW / all-reduce
@@ -407,40 +437,129 @@ class DenoiseTrainer:
         check_gemm_workspaces()
 
     # ---- HIP-graph replay of forward+backward (static shapes)
-    def capture(self, batch, warmup=2):
-        # Active dropout is captured too: the seeds frozen into the graph are offset per replay by the device-side dropout
-        # epoch that `_fwd_bwd` bumps inside the captured region (t2v_set_dropout_epoch).
+    def capture(self, batch, warmup=2, pipelined=None):
+        """Record the step as HIP graphs (static shapes).  Active dropout is captured too: the seeds frozen into the graph are
+        offset per replay by the device-side dropout epoch that `_fwd_bwd` bumps inside the captured region.
+
+        Every form records SINGLE-STREAM graphs.  Why (profiles/r04_host_timeline.txt, r04_graph_launch_probe.txt): a graph with
+        a forked branch inside (the eager step forks the frozen CLIP tower and the parameter refresh onto the auxiliary stream)
+        takes the runtime's per-node launch path — 27 ms of host time per replay here, begun only once the previous replay has
+        drained — while a single-stream graph is submitted as pre-built packets in under 1 ms without waiting, so the host runs
+        steps ahead of the device (what the data-parallel exchange and a Python training loop around the step need).
+
+        pipelined=True (default; T2V_GRAPH_PIPELINE=0 for the other form): the step as TWO single-stream graphs, twice over —
+          P_k  `_prepare`: frozen CLIP tower, VAE encode, noise, timesteps, add_noise -> prepared batch k     (k = 0, 1)
+          U_k  `_fwd_bwd` on prepared batch k: parameter refresh, UNet forward + backward, factor gradients
+        with step i replaying P_{i%2} on the auxiliary stream (as soon as U of step i-2 has released the slot, i.e. beside U of
+        step i-1) and U_{i%2} on the launch stream.  The two kinds of graph may run concurrently and therefore record into
+        separate memory pools and on separate streams (GEMM / GroupNorm scratch is per stream); the two copies of one kind are
+        serialised by stream order and share their pool.
+        pipelined=False: ONE graph on ONE stream (the auxiliary work stays on the launch stream while the capture is open);
+        T2V_GRAPH_FORK=1 restores round 3's forked single graph.
+        Same box, ms per step (profiles/r04_capture_modes.txt): forked 80.4 (host 74 per step), one stream 81.4 (host 1), pipelined
+        80.5 (host 1; the small CLIP kernels slip in beside the UNet's — the large kernels of two streams do not overlap, each
+        fills the CUs: sum of kernel durations = step time in the trace)."""
+        if pipelined is None:
+            pipelined = os.environ.get("T2V_GRAPH_PIPELINE", "1") != "0"
+        self._inline_aux = not pipelined and os.environ.get("T2V_GRAPH_FORK", "0") != "1"
+        try:
+            return self._capture(batch, warmup, pipelined)
+        finally:
+            self._inline_aux = False
+
+    def _capture(self, batch, warmup, pipelined):
         static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        side = torch.cuda.Stream()
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream()
+        # eager warm-up on the streams the graphs are recorded on: every lazily created per-stream buffer (GEMM / GroupNorm scratch,
+        # pinned staging reserve, merge tables of this dropout mode, tile-table look-ups) exists before a capture is open
+        side = self._cap_stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for _ in range(max(1, warmup)):
                 self.opt.zero_grad()
                 self._fwd_bwd(static)
         torch.cuda.current_stream().wait_stream(side)
+        if pipelined:
+            aux = self._aux()
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux):
+                self._prepare(static, side_clip=False)
+            torch.cuda.current_stream().wait_stream(aux)
         torch.cuda.synchronize()
-        self.opt.zero_grad()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._static_loss = self._fwd_bwd(static)
-        self._graph, self._static = g, static
+        self._replays = 0
+        self._pipe = None
         mods = [self.unet, self.vae] + ([self.text_encoder] if self.text_encoder is not None else [])
         self._frozen = [p for m in mods if m is not None for p in m.parameters()
                         if not p.requires_grad and "_t2v_prep" in p.__dict__]
+        if not pipelined:
+            self.opt.zero_grad()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._cap_stream):
+                self._static_loss = self._fwd_bwd(static)
+            self._graph, self._static = g, static
+            return self
+        aux = self._aux()
+        pipe, pre_pool, unet_pool = [], None, None
+        for k in range(2):
+            st = static if k == 0 else {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in static.items()}
+            g_pre = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_pre, pool=pre_pool, stream=aux):
+                prep = self._prepare(st, side_clip=False)
+            pre_pool = g_pre.pool()
+            self.opt.zero_grad()
+            g_unet = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_unet, pool=unet_pool, stream=self._cap_stream):
+                loss = self._fwd_bwd(st, prep=prep)
+            unet_pool = g_unet.pool()
+            pipe.append({"static": st, "pre": g_pre, "unet": g_unet, "prep": prep, "loss": loss,
+                         "ev_pre": torch.cuda.Event(), "ev_free": None})
+        self._pipe = pipe
+        self._graph, self._static, self._static_loss = pipe[0]["unet"], pipe[0]["static"], pipe[0]["loss"]
         return self
 
     def replay_step(self, batch=None):
+        """One optimisation step from the recorded graphs.  `batch`: new inputs for the static buffers (device tensors are
+        copied behind everything already queued on the current stream; host tensors — pinned, from a loader — go up on the
+        auxiliary stream without waiting for the running step); None = the captured batch again."""
         if self._graph is None:
             raise RuntimeError("call capture() first")
-        if batch is not None:
-            for k, v in batch.items():
-                if torch.is_tensor(v):
-                    self._static[k].copy_(v)
         if getattr(self.opt, "merge", None) is not None:
             self.opt.merge.sync_base()             # base weights re-loaded since the last step? (masters refresh in place)
         from .functional import resync_prepared
-        resync_prepared(self._frozen)              # ... and the cached bf16 copies of the unwrapped frozen layers
+        resynced = resync_prepared(self._frozen)   # ... and the cached bf16 copies of the unwrapped frozen layers
+        if self._pipe is None:
+            if batch is not None:
+                for k, v in batch.items():
+                    if torch.is_tensor(v):
+                        self._static[k].copy_(v)
+
+            def run():
+                self._graph.replay()
+                return self._static_loss
+            return self._micro_step(run)
+        slot = self._pipe[self._replays % 2]
+        self._replays += 1
+        cur, aux = torch.cuda.current_stream(), self._aux()
+        if slot["ev_free"] is not None:
+            aux.wait_event(slot["ev_free"])        # U of two steps ago has read this slot's prepared batch
+        else:
+            aux.wait_stream(cur)                   # first use: behind the capture / whatever produced the static inputs
+        if resynced or (batch is not None and any(torch.is_tensor(v) and v.is_cuda for v in batch.values())):
+            aux.wait_stream(cur)                   # device inputs / refreshed frozen copies: produced on the caller's stream
+        with torch.cuda.stream(aux):
+            if batch is not None:
+                for k, v in batch.items():
+                    if torch.is_tensor(v):
+                        slot["static"][k].copy_(v, non_blocking=True)
+            slot["pre"].replay()
+            slot["ev_pre"].record(aux)
+
         def run():
-            self._graph.replay()
-            return self._static_loss
+            cur.wait_event(slot["ev_pre"])
+            slot["unet"].replay()
+            if slot["ev_free"] is None:
+                slot["ev_free"] = torch.cuda.Event()
+            slot["ev_free"].record(cur)
+            return slot["loss"]
         return self._micro_step(run)
