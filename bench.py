@@ -423,7 +423,7 @@ def pmc_traffic():
         with open(os.path.join(ROOT, "profiles", "r04_pmc_step.json")) as f:
             j = json.load(f)
         fam = next(v for k, v in j["families"].items() if k.startswith("gemm_kernel_dma"))
-        return {"kernel_family": "gemm_kernel_dma<...> + gemm_w8_kernel<...>: all forward / backward-data launches of one C2 step",
+        return {"kernel_family": "gemm_kernel_dma<...> + gemm_w8_kernel<...> + gemm_skinny_kernel<MB>: all forward / backward-data launches of one C2 step",
                 "hbm_bytes_per_launch": fam["hbm_bytes_per_launch"], "hbm_GB_per_step": fam["hbm_GB_per_step"],
                 "launches_per_step": fam["launches_per_step"], "fetch_correction": j["fetch_correction"],
                 "source": "profiles/r04_pmc_step.json"}
@@ -441,7 +441,7 @@ def rocprof_family_time(algorithmic_flops):
         n = 0
         with open(os.path.join(ROOT, "profiles", "r04_bench_c2_kernel_stats.txt")) as f:
             for line in f:
-                if ("gemm_kernel_dma" in line or "gemm_w8_kernel" in line) and line.lstrip().startswith("_Z"):
+                if ("gemm_kernel_dma" in line or "gemm_w8_kernel" in line or "gemm_skinny_kernel" in line) and line.lstrip().startswith("_Z"):
                     parts = line.split()
                     n += int(float(parts[-4]))
                     ms += float(parts[-3])
@@ -681,7 +681,7 @@ def main():
         rr, km = both["nn"], both["kmajor"]
         ach = rr["flops"] / (rr["ms"] * 1e-3) / 1e12
         roof = dict(bound="mfma",
-                    kernel="gemm_w8_kernel<BM,BN,WM,WN,KG,NSTAGE,SCHED,BK,CS> + gemm_kernel_dma<BM,BN,WM,WN,NSTAGE> - every Linear/Conv2d/"
+                    kernel="gemm_w8_kernel<BM,BN,WM,WN,KG,NSTAGE,SCHED,BK,CS> + gemm_kernel_dma<BM,BN,WM,WN,NSTAGE> + gemm_skinny_kernel<MB> (M <= 96: the CLIP tower) - every Linear/Conv2d/"
                            "Conv3d forward and backward-data launch of one step (implicit GEMM, LDS-DMA ring; 8-wave and 4-wave "
                            "families, tile per signature from the shipped table); eager instrumented pass, HIP events on the launch stream: kernel begin/end "
                            "timestamps (hipExtLaunchKernelGGL) for single-kernel launches, an event pair around the call for split-K pairs",

@@ -12,7 +12,7 @@ import re
 import sys
 
 GEMM_LABEL = "gemm_kernel_dma<...> + gemm_w8_kernel<...> (Linear / Conv2d / Conv3d forward + backward-data, LDS-DMA ring)"
-FAMILIES = [("gemm_kernel_dma", GEMM_LABEL), ("gemm_w8_kernel", GEMM_LABEL), ("lora_drop_dt", "lora_drop_dt_kernel (masked dt of the dropped LoRA branches)"),
+FAMILIES = [("gemm_kernel_dma", GEMM_LABEL), ("gemm_w8_kernel", GEMM_LABEL), ("gemm_skinny_kernel", GEMM_LABEL), ("lora_drop_dt", "lora_drop_dt_kernel (masked dt of the dropped LoRA branches)"),
             ("lora_prep", "lora_prep_kernel"),
             ("gemm_kernel<", "gemm_kernel<..,AT|BT> (K-major operands)"), ("gemm_pair", "gemm_pair_kernel"),
             ("gemm_finalize", "gemm_finalize_kernel (split-K)"), ("lora_wgrad", "lora_wgrad_kernel (factor gradients)"),

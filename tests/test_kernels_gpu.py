@@ -28,7 +28,9 @@ def _uncl(m, n, h, w):
     return m.reshape(n, h, w, -1).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1000, 72, 136), (130, 8, 64), (4096, 640, 2560), (77, 1280, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1000, 72, 136), (130, 8, 64), (4096, 640, 2560), (77, 1280, 1024),
+                                   # M <= 96 with K % 64 == 0: the skinny weight-streaming kernel (gemm_skinny_kernel), forward and backward-data
+                                   (2, 1280, 320), (33, 1000, 128), (96, 1024, 4096), (64, 72, 64), (77, 3072, 1024)])
 def test_linear_fwd_bwd(M, N, K):
     import t2v_amd.functional as F
     g = torch.Generator().manual_seed(M + N + K)

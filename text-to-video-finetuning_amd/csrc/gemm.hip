@@ -1440,10 +1440,87 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
   return best;
 }
 
+
+// ---- skinny dense launches: M <= 96 rows (the CLIP text tower of the step: 77 tokens x 24 layers, train.py:784-790; the
+// time-embedding rows).  Such a problem is a weight stream — N*K*2 bytes read once — against <= 96 activation rows that every
+// workgroup re-reads from L2; the tiled kernels spend their launch on ring set-up, K-split slabs and a finalize pass (2 x 10-15 us
+// per layer).  Here a workgroup owns 32 output columns and its four waves split K in 64-deep chunks: a lane reads 64 contiguous
+// bytes of its weight row and of its (up to three) activation rows per chunk straight from memory — the k index is permuted
+// identically on both MFMA operands (lane half h holds k = 32h .. 32h+31 of the chunk, MFMA step s takes its s-th eight), so no
+// operand passes through LDS and the K loop has no barrier.  Weights are the FIRST MFMA operand: a lane's accumulator then holds
+// one token row and 4 x 4 consecutive output columns.  The four partial tiles meet in LDS, are summed in wave order
+// (bit-reproducible) and go through the common epilogue (finish_chunk).
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(T2VGemm p) {
+  __shared__ float red[4][MB][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+  f32x16 acc[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool nok = n0 + r < p.N;
+  const bf16_t* wrow = B + (long long)(n0 + r) * p.ldb + 32 * h;
+  const int nchunks = p.K >> 6;
+  for (int c = w; c < nchunks; c += 4) {
+    bf16x8 wf[4], xf[MB][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wf[s] = nok ? *(const bf16x8*)(wrow + (long long)c * 64 + 8 * s) : zero8;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const int row = 32 * b + r;
+      const bf16_t* xrow = A + (long long)row * p.lda + (long long)c * 64 + 32 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xf[b][s] = row < p.M ? *(const bf16x8*)(xrow + 8 * s) : zero8;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int b = 0; b < MB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], xf[b][s], acc[b], 0, 0, 0);
+  }
+  // accumulator register v of lane (r, h): output column n0 + 8 (v / 4) + 4 h + (v % 4), token row 32 b + r
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) red[w][b][8 * (v >> 2) + 4 * h + (v & 3)][r] = acc[b][v];
+  __syncthreads();
+  for (int ch = tid; ch < MB * 32 * 4; ch += 256) {
+    const int row = ch >> 2, cq = ch & 3, b = row >> 5, rl = row & 31;
+    const int col = n0 + cq * 8;
+    if (row >= p.M || col >= p.N) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (red[0][b][cq * 8 + e][rl] + red[1][b][cq * 8 + e][rl]) + (red[2][b][cq * 8 + e][rl] + red[3][b][cq * 8 + e][rl]);
+    finish_chunk(p, v, row, col, 0, 0, 0);
+  }
+}
+
+// the descriptors gemm_skinny_kernel takes: plain dense NN, one output block, no statistics / rank-wide term / batch
+bool skinny_ok(const T2VGemm& p) {
+  static const bool on = [] { const char* e = getenv("T2V_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
+  return on && p.M <= 96 && !p.a_trans && !p.b_trans && p.a_mode == T2V_A_DENSE && !p.b_conv && p.K % 64 == 0 && p.n_split <= 0 &&
+         p.lr_mode == 0 && !p.colsum && p.batch <= 1 && p.split_k <= 1 && p.out_mode == T2V_OUT_BF16;
+}
+
+int launch_skinny(const T2VGemm& p, hipStream_t s) {
+  const dim3 grid((unsigned)((p.N + 31) / 32));
+  if (p.M <= 32) T2V_LAUNCH(gemm_skinny_kernel<1>, grid, dim3(256), 0, s, p);
+  else if (p.M <= 64) T2V_LAUNCH(gemm_skinny_kernel<2>, grid, dim3(256), 0, s, p);
+  else T2V_LAUNCH(gemm_skinny_kernel<3>, grid, dim3(256), 0, s, p);
+  T2V_CHECK_LAUNCH();
+  return T2V_OK;
+}
+
 template <bool AT, bool BT>
 int dispatch(const T2VGemm& p, hipStream_t s) {
   constexpr bool DMA = !AT && !BT;
   if constexpr (DMA) {
+    if (skinny_ok(p)) return launch_skinny(p, s);
     if (p.split_k <= 1 && !g_force_regstage) return launch_dma_cfg(p, pick_cfg(p, s), s);
   }
   T2V_CHECK_ARG(p.lr_mode == 0, "t2v_gemm: a rank-wide epilogue term (lr_mode) needs the NN LDS-DMA path");
@@ -1623,6 +1700,11 @@ extern "C" int t2v_gemm_lr_ok(const T2VGemm* pp) {
 
 extern "C" int t2v_gemm_colsum_rows(const T2VGemm* pp) {
   if (!pp || !w8_ok(*pp) || check_gemm(*pp) != T2V_OK) return 0;
+  {
+    T2VGemm q = *pp;
+    q.colsum = nullptr;
+    if (skinny_ok(q)) return 0;                               // (the skinny kernel emits no column statistics)
+  }
   if (g_autotune < 0) {
     const char* e = getenv("T2V_GEMM_AUTOTUNE");
     g_autotune = !e ? 1 : (e[0] == '0' ? 0 : ((e[0] == 'l' || e[0] == '2') ? 2 : 1));
