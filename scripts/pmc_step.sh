@@ -4,7 +4,7 @@
 # steps each.  Per-kernel totals -> gpurun_out/<tag>_{FETCH_SIZE,WRITE_SIZE}.txt (scripts/rocpd_pmc.py); summarised into
 # profiles/ by scripts/pmc_summary.py.   usage (GPU box): bash scripts/pmc_step.sh <tag>
 tag=${1:-pmc_step}
-# counter collection serialises dispatches: the two-stream (pipelined) replay then dead-locks on its cross-stream events
+# counter collection serialises dispatches: a two-stream (pipelined) replay then dead-locks on its cross-stream events
 # (r04: 1666 incomplete dispatches after 8 minutes) -> the counter passes run the one-graph / one-stream capture form
 export T2V_GRAPH_PIPELINE=0
 root=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -447,20 +447,26 @@ class DenoiseTrainer:
         drained — while a single-stream graph is submitted as pre-built packets in under 1 ms without waiting, so the host runs
         steps ahead of the device (what the data-parallel exchange and a Python training loop around the step need).
 
-        pipelined=True (default; T2V_GRAPH_PIPELINE=0 for the other form): the step as TWO single-stream graphs, twice over —
+        pipelined=False (default): ONE graph on ONE stream — the frozen CLIP tower and the parameter refresh, which the eager step
+        forks onto the auxiliary stream, stay on the launch stream while the capture is open.  T2V_GRAPH_FORK=1 restores round
+        3's forked single graph.
+        pipelined=True (T2V_GRAPH_PIPELINE=1; experimental): the step as TWO single-stream graphs, twice over —
           P_k  `_prepare`: frozen CLIP tower, VAE encode, noise, timesteps, add_noise -> prepared batch k     (k = 0, 1)
           U_k  `_fwd_bwd` on prepared batch k: parameter refresh, UNet forward + backward, factor gradients
         with step i replaying P_{i%2} on the auxiliary stream (as soon as U of step i-2 has released the slot, i.e. beside U of
         step i-1) and U_{i%2} on the launch stream.  The two kinds of graph may run concurrently and therefore record into
         separate memory pools and on separate streams (GEMM / GroupNorm scratch is per stream); the two copies of one kind are
-        serialised by stream order and share their pool.
-        pipelined=False: ONE graph on ONE stream (the auxiliary work stays on the launch stream while the capture is open);
-        T2V_GRAPH_FORK=1 restores round 3's forked single graph.
+        serialised by stream order and share their pool.  Not the default: with P truly running beside U (host inputs, or the
+        captured batch again) one step of six sat 3e-3 off the eager loss in every run of
+        tests/test_train_gpu.py::test_pipelined_replays_without_host_sync_follow_the_eager_trajectory[True] (inside the test's
+        5e-3 bar, 5x the other steps and systematic) — unexplained, so the form that never runs two queues at once is what
+        ships; and a replay right behind an asynchronous host-to-device copy started before the copy had landed (fixed here
+        by uploading through a temporary + copy kernel).
         Same box, ms per step (profiles/r04_capture_modes.txt): forked 80.4 (host 74 per step), one stream 81.4 (host 1), pipelined
         80.5 (host 1; the small CLIP kernels slip in beside the UNet's — the large kernels of two streams do not overlap, each
         fills the CUs: sum of kernel durations = step time in the trace)."""
         if pipelined is None:
-            pipelined = os.environ.get("T2V_GRAPH_PIPELINE", "1") != "0"
+            pipelined = os.environ.get("T2V_GRAPH_PIPELINE", "0") == "1"
         self._inline_aux = not pipelined and os.environ.get("T2V_GRAPH_FORK", "0") != "1"
         try:
             return self._capture(batch, warmup, pipelined)
@@ -551,7 +557,13 @@ class DenoiseTrainer:
             if batch is not None:
                 for k, v in batch.items():
                     if torch.is_tensor(v):
-                        slot["static"][k].copy_(v, non_blocking=True)
+                        if not v.is_cuda:
+                            # host input: upload into a temporary, then a device-side copy into the static buffer.  A graph
+                            # replayed right behind an asynchronous host-to-device copy on the same stream started before the
+                            # copy had landed (packet-path launch; tests/test_train_gpu.py::test_pipelined_replays..[True]
+                            # read the previous contents) — the copy KERNEL is ordered like every other dispatch.
+                            v = v.to(slot["static"][k].device, non_blocking=True)
+                        slot["static"][k].copy_(v)
             slot["pre"].replay()
             slot["ev_pre"].record(aux)
 
