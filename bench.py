@@ -426,7 +426,7 @@ def pmc_traffic():
         return {"kernel_family": "gemm_kernel_dma<...> + gemm_w8_kernel<...> + gemm_skinny_kernel<MB>: all forward / backward-data launches of one C2 step",
                 "hbm_bytes_per_launch": fam["hbm_bytes_per_launch"], "hbm_GB_per_step": fam["hbm_GB_per_step"],
                 "launches_per_step": fam["launches_per_step"], "fetch_correction": j["fetch_correction"],
-                "source": "profiles/r04_pmc_step.json"}
+                "source": "profiles/r04_pmc_step.json", "note": j.get("note")}
     except Exception:   # noqa: BLE001
         return None
 
