@@ -241,6 +241,12 @@ class DenoiseTrainer:
     """One optimisation step = VAE encode -> noise/add_noise -> 2x UNet forward -> eps-MSE -> backward ->
     (RCCL all-reduce of the flat LoRA gradient) -> clip -> AdamW."""
 
+    # capture state (class-level defaults: helpers that borrow `loss_fn` build the object without __init__, tests/test_dp_gpu.py)
+    _inline_aux = False
+    _pipe = None
+    _cap_stream = None
+    _aux_stream = None
+
     def __init__(self, unet, vae, params, lr=5e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
                  scheduler=None, process_group=None, world_size=1, text_encoder=None, use_offset_noise=False,
                  offset_noise_strength=0.1, rescale_schedule=False, cache_latents=False, gradient_accumulation_steps=1,
