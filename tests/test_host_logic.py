@@ -574,3 +574,44 @@ def test_native_unet_refuses_attention_mask_and_odd_grids():
     import t2v_amd.models.unet_3d_condition as m
     src = inspect.getsource(m.UNet3DConditionModel.forward)
     assert "attention_mask is not None" in src and "upsample_size" in src
+
+
+def test_merge_plan_refreshes_only_the_weights_that_are_read():
+    """Default train mode (utils/lora.py:35,89 vs :179): wrappers whose dropout is active never read W_eff, so the merge plan must
+    pick the non-dropping entries only, take a projection group as a whole or not at all, and mark every skipped entry stale
+    (merge_scale None) so that a layer can never read a merged weight that was not refreshed.  Host logic only (no device)."""
+    import torch.nn as nn
+    from t2v_amd.lora_bank import LoraEntry, LoraGroup, MergePlan
+
+    class Wrapper(nn.Module):
+        def __init__(self, p):
+            super().__init__()
+            self.dropout = nn.Dropout(p) if p is not None else nn.Identity()
+            self.scale = 0.5
+
+    def entry(group=None):
+        e = LoraEntry()
+        e.group, e.merge_scale = group, None
+        return e
+    g_mixed, g_off = LoraGroup(), LoraGroup()
+    mods = [Wrapper(0.1), Wrapper(0.0), Wrapper(None),            # 0 drops, 1 / 2 do not
+            Wrapper(0.0), Wrapper(0.1),                            # 3, 4: one group, one member drops -> neither is merged
+            Wrapper(0.0), Wrapper(0.0)]                            # 5, 6: a group that stays merged
+    ents = [entry(), entry(), entry(), entry(g_mixed), entry(g_mixed), entry(g_off), entry(g_off)]
+    for g, idx in ((g_mixed, (3, 4)), (g_off, (5, 6))):
+        g.mods, g.merge_scale = [mods[i] for i in idx], None
+    plan = MergePlan.__new__(MergePlan)
+    plan.entries = list(zip(ents, mods))
+    for m in mods:
+        m.train()
+    assert plan.wanted() == (1, 2, 5, 6)
+    plan._mark(plan.wanted())
+    assert [e.merge_scale for e in ents] == [None, 0.5, 0.5, None, None, 0.5, 0.5]
+    assert g_mixed.merge_scale is None and g_off.merge_scale == 0.5
+    for m in mods:
+        m.eval()                                                   # eval_train mode: every Dropout off -> everything merged
+    assert plan.wanted() == tuple(range(7))
+    plan._mark(plan.wanted())
+    assert all(e.merge_scale == 0.5 for e in ents) and g_mixed.merge_scale == 0.5
+    plan._mark(())
+    assert all(e.merge_scale is None for e in ents) and g_off.merge_scale is None
