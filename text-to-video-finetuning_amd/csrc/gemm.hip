@@ -1500,6 +1500,83 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(T2VGemm p) {
   }
 }
 
+// Eight-wave variant (T2V_GEMM_SKINNY=2; NOT yet the default — written after the round's GPU time was spent, to be measured):
+// the four-wave kernel above is latency-bound as it stands (17.9 us per CLIP layer in the step: one dependent round trip per
+// 64-deep chunk and wave, four of them at K = 1024, sixteen at K = 4096).  Here eight waves split K and every wave keeps TWO
+// chunks in flight (both chunks' loads are issued before the first MFMA), i.e. one round trip at K = 1024 and four at 4096;
+// the eight partial tiles are folded in two stages through the same 50 KB of LDS (waves 4-7 park theirs, waves 0-3 add them to
+// their registers in a fixed order and park the sums, the epilogue adds the four) — bit-reproducible like the four-wave form.
+template <int MB>
+__global__ __launch_bounds__(512) void gemm_skinny8_kernel(T2VGemm p) {
+  __shared__ float red[4][MB][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+  f32x16 acc[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool nok = n0 + r < p.N;
+  const bf16_t* wrow = B + (long long)(n0 + r) * p.ldb + 32 * h;
+  const int nchunks = p.K >> 6;
+  auto load = [&](int c, bf16x8 (&wf)[4], bf16x8 (&xf)[MB][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wf[s] = nok ? *(const bf16x8*)(wrow + (long long)c * 64 + 8 * s) : zero8;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const int row = 32 * b + r;
+      const bf16_t* xrow = A + (long long)row * p.lda + (long long)c * 64 + 32 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xf[b][s] = row < p.M ? *(const bf16x8*)(xrow + 8 * s) : zero8;
+    }
+  };
+  auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[MB][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int b = 0; b < MB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], xf[b][s], acc[b], 0, 0, 0);
+  };
+  for (int c = w; c < nchunks; c += 16) {
+    bf16x8 wf0[4], xf0[MB][4], wf1[4], xf1[MB][4];
+    const bool two = c + 8 < nchunks;              // wave-uniform
+    load(c, wf0, xf0);
+    if (two) load(c + 8, wf1, xf1);
+    mma(wf0, xf0);
+    if (two) mma(wf1, xf1);
+  }
+  // accumulator register v of lane (r, h): output column n0 + 8 (v / 4) + 4 h + (v % 4), token row 32 b + r
+  if (w >= 4) {
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) red[w - 4][b][8 * (v >> 2) + 4 * h + (v & 3)][r] = acc[b][v];
+  }
+  __syncthreads();
+  if (w < 4) {
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        float* q = &red[w][b][8 * (v >> 2) + 4 * h + (v & 3)][r];
+        *q = acc[b][v] + *q;                         // wave w + (wave w + 4): the same lane wrote and reads this slot
+      }
+  }
+  __syncthreads();
+  for (int ch = tid; ch < MB * 32 * 4; ch += 512) {
+    const int row = ch >> 2, cq = ch & 3, b = row >> 5, rl = row & 31;
+    const int col = n0 + cq * 8;
+    if (row >= p.M || col >= p.N) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (red[0][b][cq * 8 + e][rl] + red[1][b][cq * 8 + e][rl]) + (red[2][b][cq * 8 + e][rl] + red[3][b][cq * 8 + e][rl]);
+    finish_chunk(p, v, row, col, 0, 0, 0);
+  }
+}
+
 // the descriptors gemm_skinny_kernel takes: plain dense NN, one output block, no statistics / rank-wide term / batch
 bool skinny_ok(const T2VGemm& p) {
   static const bool on = [] { const char* e = getenv("T2V_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
@@ -1509,6 +1586,14 @@ bool skinny_ok(const T2VGemm& p) {
 
 int launch_skinny(const T2VGemm& p, hipStream_t s) {
   const dim3 grid((unsigned)((p.N + 31) / 32));
+  static const bool eight = [] { const char* e = getenv("T2V_GEMM_SKINNY"); return e && e[0] == '2'; }();
+  if (eight) {
+    if (p.M <= 32) T2V_LAUNCH(gemm_skinny8_kernel<1>, grid, dim3(512), 0, s, p);
+    else if (p.M <= 64) T2V_LAUNCH(gemm_skinny8_kernel<2>, grid, dim3(512), 0, s, p);
+    else T2V_LAUNCH(gemm_skinny8_kernel<3>, grid, dim3(512), 0, s, p);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+  }
   if (p.M <= 32) T2V_LAUNCH(gemm_skinny_kernel<1>, grid, dim3(256), 0, s, p);
   else if (p.M <= 64) T2V_LAUNCH(gemm_skinny_kernel<2>, grid, dim3(256), 0, s, p);
   else T2V_LAUNCH(gemm_skinny_kernel<3>, grid, dim3(256), 0, s, p);
