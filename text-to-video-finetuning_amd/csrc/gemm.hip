@@ -1577,6 +1577,140 @@ __global__ __launch_bounds__(512) void gemm_skinny8_kernel(T2VGemm p) {
   }
 }
 
+// K split ACROSS workgroups (T2V_GEMM_SKINNY=3; NOT the default — written after the round's GPU time was spent, to be measured).
+// What the probe of the two kernels above showed on hardware (profiles/r04_skinny_probe.txt + the step's trace): both take the same
+// time (35 us at N = 1024, K = 4096; ~9 us at K = 1024), i.e. the bound is not the number of dependent round trips per wave but
+// the bytes ONE compute unit pulls with four or eight waves (~25 GB/s: 256 KB of weights + 630 KB of re-read activations per
+// workgroup at K = 4096) while 224 of the 256 CUs idle.  Here grid.y = KP workgroups share a column block, each owns a contiguous
+// K part (two chunks in flight per wave), reduces its four waves through LDS as above and hands its 77 x 32 partial over with the
+// in-launch split-K protocol of gemm_w8.hip (ticket; writers: plain stores -> vmcnt(0) -> barrier -> lane-0 agent release ->
+// done mark; the LAST arriver waits for the marks, acquires, and sums the slabs IN SPLIT ORDER with its own partial in its
+// place: bit-reproducible whoever comes last).  Workspace: counters of column block nb at words 2 nb, 2 nb + 1 of the first
+// 64 KB (left zero), slabs behind it.
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_skinnyk_kernel(T2VGemm p, int KP) {
+  __shared__ float red[4][MB][32][33];
+  __shared__ int s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nb = blockIdx.x, z = blockIdx.y, n0 = nb * 32;
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+  f32x16 acc[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool nok = n0 + r < p.N;
+  const bf16_t* wrow = B + (long long)(n0 + r) * p.ldb + 32 * h;
+  const int per = (p.K >> 6) / KP;                      // chunks of this K part (the launcher makes KP divide the chunk count)
+  const int c_end = (z + 1) * per;
+  auto load = [&](int c, bf16x8 (&wf)[4], bf16x8 (&xf)[MB][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wf[s] = nok ? *(const bf16x8*)(wrow + (long long)c * 64 + 8 * s) : zero8;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const int row = 32 * b + r;
+      const bf16_t* xrow = A + (long long)row * p.lda + (long long)c * 64 + 32 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xf[b][s] = row < p.M ? *(const bf16x8*)(xrow + 8 * s) : zero8;
+    }
+  };
+  auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[MB][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int b = 0; b < MB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], xf[b][s], acc[b], 0, 0, 0);
+  };
+  for (int c = z * per + w; c < c_end; c += 8) {
+    bf16x8 wf0[4], xf0[MB][4], wf1[4], xf1[MB][4];
+    const bool two = c + 4 < c_end;                  // wave-uniform
+    load(c, wf0, xf0);
+    if (two) load(c + 4, wf1, xf1);
+    mma(wf0, xf0);
+    if (two) mma(wf1, xf1);
+  }
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) red[w][b][8 * (v >> 2) + 4 * h + (v & 3)][r] = acc[b][v];
+  __syncthreads();
+  // item ch = (token row ch >> 2, column chunk ch & 3); a thread owns items tid and tid + 256
+  constexpr int ITEMS = MB * 32 * 4, NIT = (ITEMS + 255) / 256;
+  float v[NIT][8];
+  bool live[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int ch = tid + 256 * i, row = ch >> 2, cq = ch & 3, b = row >> 5, rl = row & 31;
+    live[i] = ch < ITEMS && row < p.M && n0 + cq * 8 < p.N;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[i][e] = live[i] ? (red[0][b][cq * 8 + e][rl] + red[1][b][cq * 8 + e][rl]) + (red[2][b][cq * 8 + e][rl] + red[3][b][cq * 8 + e][rl]) : 0.f;
+  }
+  if (KP > 1) {
+    unsigned* cnt = (unsigned*)p.workspace + 2 * nb;
+    float* slab0 = (float*)((unsigned char*)p.workspace + 65536) + (long long)nb * KP * (ITEMS * 8);
+    if (tid == 0) s_ticket = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool reducer = s_ticket == KP - 1;
+    if (!reducer) {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+        if (live[i]) {
+          float4* sp = (float4*)(slab0 + ((long long)z * ITEMS + tid + 256 * i) * 8);
+          sp[0] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+          sp[1] = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's slab rows have left
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the compiler may drop the fence's own wait, guide G16)
+        __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(KP - 1)) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 24)) {                   // give up instead of hanging the device; read by check_gemm_workspaces()
+          ((unsigned*)p.workspace)[16383] = 0xdeadu;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // re-armed for the next launch
+      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      if (!live[i]) continue;
+      float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int z2 = 0; z2 < KP; ++z2) {              // split order, own partial in its place
+        if (z2 == z) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] += v[i][e];
+        } else {
+          const float4* sp = (const float4*)(slab0 + ((long long)z2 * ITEMS + tid + 256 * i) * 8);
+          const float4 a = sp[0], c = sp[1];
+          t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += c.x; t[5] += c.y; t[6] += c.z; t[7] += c.w;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = t[e];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i)
+    if (live[i]) {
+      const int ch = tid + 256 * i;
+      finish_chunk(p, v[i], ch >> 2, n0 + (ch & 3) * 8, 0, 0, 0);
+    }
+}
+
 // the descriptors gemm_skinny_kernel takes: plain dense NN, one output block, no statistics / rank-wide term / batch
 bool skinny_ok(const T2VGemm& p) {
   static const bool on = [] { const char* e = getenv("T2V_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
@@ -1586,7 +1720,23 @@ bool skinny_ok(const T2VGemm& p) {
 
 int launch_skinny(const T2VGemm& p, hipStream_t s) {
   const dim3 grid((unsigned)((p.N + 31) / 32));
-  static const bool eight = [] { const char* e = getenv("T2V_GEMM_SKINNY"); return e && e[0] == '2'; }();
+  static const int variant = [] { const char* e = getenv("T2V_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+  if (variant == 3) {
+    // K parts: enough workgroups for the chip (~256), at least four chunks (one per wave) each, a power of two that divides the
+    // chunk count, and slabs that fit the caller's scratch
+    const int nchunks = p.K >> 6, nb = (p.N + 31) / 32, mb = p.M <= 32 ? 1 : (p.M <= 64 ? 2 : 3);
+    int kp = 1;
+    while (kp * 2 * nb <= 256 && nchunks % (kp * 2) == 0 && nchunks / (kp * 2) >= 4) kp *= 2;
+    const size_t need = 65536 + (size_t)nb * kp * mb * 32 * 32 * 4;
+    if (kp > 1 && (!p.workspace || p.workspace_bytes < need || 2 * nb + 1 >= 16383)) kp = 1;
+    const dim3 g3((unsigned)nb, (unsigned)kp);
+    if (mb == 1) T2V_LAUNCH(gemm_skinnyk_kernel<1>, g3, dim3(256), 0, s, p, kp);
+    else if (mb == 2) T2V_LAUNCH(gemm_skinnyk_kernel<2>, g3, dim3(256), 0, s, p, kp);
+    else T2V_LAUNCH(gemm_skinnyk_kernel<3>, g3, dim3(256), 0, s, p, kp);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+  }
+  const bool eight = variant == 2;
   if (eight) {
     if (p.M <= 32) T2V_LAUNCH(gemm_skinny8_kernel<1>, grid, dim3(512), 0, s, p);
     else if (p.M <= 64) T2V_LAUNCH(gemm_skinny8_kernel<2>, grid, dim3(512), 0, s, p);
