@@ -30,3 +30,5 @@ for M, N, K in ((77, 3072, 1024), (77, 1024, 1024), (77, 4096, 1024), (77, 1024,
         e.record()
         torch.cuda.synchronize()
     print(f"SKINNY={mode} M={M} N={N} K={K}: rel err {err:.2e}, {s.elapsed_time(e) / 200 * 1e3:.1f} us per call (eager, incl. dispatch gap)")
+F.check_gemm_workspaces()
+print(f"SKINNY={mode}: no split-K give-up flag")
