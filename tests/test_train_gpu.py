@@ -192,7 +192,8 @@ def test_pipelined_replays_without_host_sync_follow_the_eager_trajectory(host_ba
         print(f"step {i}: replay {a.item():.6f} eager {b.item():.6f} rel {rel:.2e}")
         # step 0 is exact (and step 1 was in every run); later steps sit 3e-4 .. 9e-4 off (AdamW's sign-like first updates
         # amplify 1-ulp differences) — except step 3 of the host-batch run, where the prepare graph truly runs beside the previous
-        # UNet graph: 2.8e-3 .. 3.7e-3 in five runs out of five (unexplained; the reason this form is opt-in).  The bar
+        # UNet graph: 2.8e-3 .. 3.7e-3 in five runs out of five while the two prepare graphs shared one memory pool (slot 1's
+        # batch sat on the other graph's intermediates; separate pools since, not yet re-measured).  The bar
         # below catches a wrong input (the un-ordered upload this test found read 1.3e-2 at step 1), not that deviation.
         assert rel < (1e-5 if i == 0 else (1e-2 if host_batches else 5e-3))
     assert len({round(v.item(), 5) for v in want}) == 6          # the batches really differ

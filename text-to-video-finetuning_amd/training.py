@@ -425,7 +425,9 @@ class DenoiseTrainer:
             raise
         self._micro += 1
         # the reference logs / gathers the MEAN loss of the window's micro-steps (accelerate divides each by the window length)
-        self._window_loss = loss if self._window_loss is None else self._window_loss + loss
+        # (a replayed graph hands back the SAME static tensor every time: the window's running sum must own its memory)
+        if self.gas > 1:
+            self._window_loss = loss.clone() if self._window_loss is None else self._window_loss + loss
         if self._micro < self.gas:
             return loss
         self._micro = 0
@@ -462,12 +464,15 @@ class DenoiseTrainer:
         with step i replaying P_{i%2} on the auxiliary stream (as soon as U of step i-2 has released the slot, i.e. beside U of
         step i-1) and U_{i%2} on the launch stream.  The two kinds of graph may run concurrently and therefore record into
         separate memory pools and on separate streams (GEMM / GroupNorm scratch is per stream); the two copies of one kind are
-        serialised by stream order and share their pool.  Not the default: with P truly running beside U (host inputs, or the
-        captured batch again) one step of six sat 3e-3 off the eager loss in every run of
-        tests/test_train_gpu.py::test_pipelined_replays_without_host_sync_follow_the_eager_trajectory[True] (inside the test's
-        5e-3 bar, 5x the other steps and systematic) — unexplained, so the form that never runs two queues at once is what
-        ships; and a replay right behind an asynchronous host-to-device copy started before the copy had landed (fixed here
-        by uploading through a temporary + copy kernel).
+        serialised by stream order.  Not the default: it was measured with the two P graphs sharing one memory pool, and with P
+        truly running beside U (host inputs, or the captured batch again) step 3 of six sat 3e-3 off the eager loss in every run
+        of tests/test_train_gpu.py::test_pipelined_replays_without_host_sync_follow_the_eager_trajectory[True].  The likely cause,
+        found after the round's GPU time was spent: slot 1's prepared batch was allocated during the second capture on blocks
+        the first P graph had used for intermediates, so P of step 4 (slot 0) wrote over the batch U of step 3 was reading (only
+        an odd step with a successor and a host that is already running ahead shows it — exactly step 3 of six).  Every P graph
+        now records into its own pool; until that is confirmed on hardware the form stays opt-in.  A second lesson from the same
+        test: a replay right behind an asynchronous host-to-device copy started before the copy had landed (host inputs now go
+        up through a temporary + copy kernel).
         Same box, ms per step (profiles/r04_capture_modes.txt): forked 80.4 (host 74 per step), one stream 81.4 (host 1), pipelined
         80.5 (host 1; the small CLIP kernels slip in beside the UNet's — the large kernels of two streams do not overlap, each
         fills the CUs: sum of kernel durations = step time in the trace)."""
@@ -512,13 +517,16 @@ class DenoiseTrainer:
             self._graph, self._static = g, static
             return self
         aux = self._aux()
-        pipe, pre_pool, unet_pool = [], None, None
+        pipe, unet_pool = [], None
         for k in range(2):
             st = static if k == 0 else {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in static.items()}
             g_pre = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_pre, pool=pre_pool, stream=aux):
+            # every P graph records into a pool of its OWN: P of step i+1 (the other slot) runs beside U of step i, which reads this
+            # slot's prepared batch — in a shared pool that batch may sit on memory the other P graph uses for its intermediates
+            # (blocks freed at the end of the first capture are handed out again in the second).  The U graphs are serialised on
+            # the launch stream and share theirs.
+            with torch.cuda.graph(g_pre, stream=aux):
                 prep = self._prepare(st, side_clip=False)
-            pre_pool = g_pre.pool()
             self.opt.zero_grad()
             g_unet = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_unet, pool=unet_pool, stream=self._cap_stream):
