@@ -152,6 +152,10 @@ typedef struct {
    * m * Nb + n) ? y / (1 - cs_drop_p) : 0 — what t2v_gn_bwd_stats does with its drop_p / drop_seed.  0: no dropout. */
   float cs_drop_p; unsigned long long cs_drop_seed;
 } T2VGemm;
+/* Kernel selection is the library's: the shipped tile table / heuristic picks a 4-wave or an 8-wave tiled kernel; a plain dense
+ * NN descriptor with M <= 96 and K % 64 == 0 (no rank columns, statistics, rank-wide term or batch; bf16 output) runs on the
+ * skinny weight-streaming kernel (the CLIP text tower's 77-token layers, train.py:784-790; T2V_GEMM_SKINNY=0 switches it off) —
+ * same arithmetic (fp32 accumulation, one bf16 rounding in the epilogue), fixed summation order. */
 int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
 /* Tile rows BMt of the kernel t2v_gemm will run for this descriptor if that kernel can emit `colsum`, else 0 (deterministic:
  * shipped tile table / heuristic; 0 during live tuning runs). */
