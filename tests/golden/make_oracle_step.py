@@ -7,12 +7,17 @@
     python tests/golden/make_oracle_step.py --config c3full        (the same on configs[2]'s own clip: 16 frames @256x256)
     python tests/golden/make_oracle_step.py --config c1 --scales 0.02 --dropout   (default train mode, restated masks)
     python tests/golden/make_oracle_step.py --config c2 --scales 0.02 --dropout   (the same at the benchmark configuration)
+    ... --floor        (C1, no dropout) also runs the oracle under torch.autocast(cpu, bf16) — the reference's own recipe,
+                       train.py:848-852 — and records ITS per-tensor error for the tensors stored in full
 
 For ModelScope-1.7B shapes with host-seeded weights/inputs (tests/parity_utils.py) the CPU fp32 oracle evaluates the
 eps-MSE of train.py:793-834 and its gradients w.r.t. all 1148 LoRA factors.  Recorded per fixture:
   loss, weight checksum, per-tensor gradient norms, 4 seeded +-1 random projections of EVERY gradient tensor (a complete
-  sketch: a mis-laid-out tensor decorrelates its projections), and the exact values (first 8192 elements) of a sample of
-  tensors covering every layer kind.
+  sketch: a mis-laid-out tensor decorrelates its projections), the exact values (first 8192 elements) of a sample of
+  tensors covering every layer kind, and (round 5) `big`: the COMPLETE fp32 gradient of every tensor holding >= 1 % of the
+  gradient norm — the per-tensor gate compares these element by element (a 4-projection estimate of one tensor's error is a
+  chi^2_4 variable: it reads 0.4x .. 1.6x the true value, which is what tripped the round-4 gate) — with `big_floor`, the
+  error of the bf16-autocast oracle on the same tensors where `--floor` was given.
 The GPU tests (tests/test_lora_grads_gpu.py) rebuild the same weights, verify the checksum, and compare the native path.
 """
 import argparse
@@ -45,6 +50,44 @@ def sketch(name, t):
     return (projection_signs(name, v.numel()).double() @ v).float()
 
 
+def sketch_big(name, t):
+    """Count-sketch of a large tensor: one seeded +-1 sign per element, elements folded into NPROJ_BIG buckets
+    (y_j = sum over i = j mod NPROJ_BIG of d_i v_i).  E sum_j (y_j - y'_j)^2 = ||v - v'||^2 with the spread of a chi^2_64 variable
+    (+-18 % on the square, +-9 % on the error itself), at one random draw per element (a 14.7 M-element weight: 0.2 s)."""
+    v = t.detach().double().flatten()
+    seed = int.from_bytes(hashlib.sha256(("big:" + name).encode()).digest()[:6], "little")
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randint(0, 2, (v.numel(),), generator=g, dtype=torch.int8).double() * 2 - 1
+    w = d * v
+    pad = (-w.numel()) % NPROJ_BIG
+    if pad:
+        w = torch.cat([w, w.new_zeros(pad)])
+    return w.view(-1, NPROJ_BIG).sum(0)
+
+
+BIG_SHARE = 1e-2        # tensors holding >= 1 % of the gradient norm are stored in full ...
+BIG_FULL_NUMEL = 65536  # ... up to this size; larger ones (rank-16 down factors of 3x3 convs, full-finetune weights) as
+NPROJ_BIG = 64          # a 64-bucket count-sketch: the error estimate of ONE tensor is then good to +-9 % (chi^2_64) instead of +-2x
+
+
+def autocast_floor_of(unet, vae, batch, big):
+    """Per-tensor relative error of the SAME oracle under torch.autocast(cpu, bfloat16) (the reference's mixed-precision
+    recipe, train.py:848-852; fp32 latents for both arms as in scripts/autocast_floor.py) on the tensors of `big`."""
+    from oracle.fastconv import fast_temporal_conv3d
+    from oracle.train_step import finetune_unet_loss
+    from oracle.vae import tensor_to_vae_latent
+    for p in unet.parameters():
+        p.grad = None
+    with torch.no_grad():
+        latents = tensor_to_vae_latent(batch["pixel_values"], vae, batch["vae_eps"])
+    with fast_temporal_conv3d():
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            loss, _ = finetune_unet_loss(unet, vae, batch, cached_latents=latents)
+        loss.backward()
+    g16 = {n: p.grad.detach().double() for n, p in unet.named_parameters() if p.requires_grad and n in big}
+    return {n: float((g16[n] - v.double()).norm() / v.double().norm()) for n, v in big.items()}
+
+
 def sample_names(names):
     names = sorted(names)
     pick = set(names[::24])
@@ -61,6 +104,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c1")
     ap.add_argument("--scales", default="0,0.02,0.2")
+    ap.add_argument("--floor", action="store_true",
+                    help="also run the oracle under torch.autocast(cpu, bfloat16) and record its per-tensor error on the `big` tensors")
     ap.add_argument("--dropout", action="store_true",
                     help="the reference's DEFAULT train mode: LoRA dropout 0.1 + TemporalConvLayer dropout 0.1, with the masks of "
                          "the native protocol restated on the CPU (oracle/dropout.py; first step of a fresh trainer)")
@@ -89,15 +134,25 @@ def main():
         if args.dropout:
             assert ctx["k"] == 1, "both passes must have run through the protocol"
         total = sum(float(g.double().pow(2).sum()) for g in grads.values()) ** 0.5
+        big_names = [n for n, g in grads.items() if float(g.double().pow(2).sum()) >= BIG_SHARE ** 2 * total ** 2]
+        big = {n: grads[n].detach().float().clone() for n in big_names if grads[n].numel() <= BIG_FULL_NUMEL}
+        big_sketch = {n: sketch_big(n, grads[n]) for n in big_names if grads[n].numel() > BIG_FULL_NUMEL}
+        big_floor = {}
+        if args.floor:
+            assert not args.dropout and args.config == "c1", "the floor arm re-runs the two-pass step: C1, eval_train mode"
+            big_floor = autocast_floor_of(unet, vae, batch, {n: grads[n] for n in big_names})
         fx = dict(dropout=bool(args.dropout), config=args.config, frames=frames, height=H, width=W, rank=r, lora_up_scale=scale, seed=0, batch_seed=1234,
                   loss=loss, n_wrapped=n_wrapped, checksum=pu.weight_checksum(unet, vae), grad_norm=total,
                   grad_norms={n: float(g.double().norm()) for n, g in grads.items()},
                   sketches={n: sketch(n, g) for n, g in grads.items()},
                   samples={n: grads[n].flatten()[:8192].clone() for n in sample_names(grads)},
+                  big=big, big_sketch=big_sketch, big_floor=big_floor, big_share=BIG_SHARE,
                   torch_version=torch.__version__)
         path = pu.fixture_path(args.config, scale, dropout=args.dropout)
-        torch.save(fx, path)
-        print(f"{path}: loss {loss:.6f} |g| {total:.4e} tensors {len(grads)} samples {len(fx['samples'])} "
+        torch.save(fx, path + ".tmp")
+        os.replace(path + ".tmp", path)          # (atomic: a gpurun snapshot taken meanwhile never sees half a file)
+        print(f"{path}: loss {loss:.6f} |g| {total:.4e} tensors {len(grads)} samples {len(fx['samples'])} big {len(big)}+{len(big_sketch)} "
+              f"floor max {max(big_floor.values()) if big_floor else float('nan'):.3f} "
               f"({os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s)", flush=True)
 
 

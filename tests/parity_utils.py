@@ -6,6 +6,7 @@ fixtures: the GPU box rebuilds the identical weights/inputs, checks their checks
 native path with the recorded oracle loss / LoRA-factor gradients.  If the checksum does not match (different torch
 build), the tests fall back to running the oracle live.
 """
+import json
 import os
 
 import torch
@@ -217,3 +218,36 @@ def fixture_path(config, scale, dropout=False):
 
 def sampled_names(names, every=12):
     return sorted(names)[::every]
+
+
+# ---------------------------------------------------------------------------------------------- shared by the model-level parity tests
+FLOOR_FACTOR = 2.0          # a native result is accepted within 2x the error of the reference's own bf16 recipe (autocast floor)
+RESULTS = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "parity_r05.jsonl")
+
+
+def floor_row(config, scale):
+    """Row of tests/golden/autocast_floor_<config>.json (scripts/autocast_floor.py) nearest to the `lora_up` amplitude."""
+    with open(os.path.join(GOLDEN, f"autocast_floor_{config}.json")) as f:
+        rows = json.load(f)["rows"]
+    return min(rows, key=lambda r: abs(r["lora_up_scale"] - scale))
+
+
+def record(**kw):
+    """Append one result row to gpurun_out/parity_r05.jsonl (copied to profiles/ after a GPU run) and print it."""
+    try:
+        os.makedirs(os.path.dirname(RESULTS), exist_ok=True)
+        with open(RESULTS, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+    print(json.dumps(kw))
+
+
+def set_lora_up(ounet, dunet, scale):
+    from oracle.weights import randomize_lora_up
+    randomize_lora_up(ounet, scale=scale)
+    od = dict(ounet.named_parameters())
+    with torch.no_grad():
+        for n, p in dunet.named_parameters():
+            if p.requires_grad:
+                p.copy_(od[n])          # p.data is a view of the trainer's flat fp32 buffer

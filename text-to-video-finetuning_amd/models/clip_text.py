@@ -46,12 +46,37 @@ def _qkv_fused(a):
         return None
     tag = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
     hit = a.__dict__.get("_t2v_qkv")
-    if hit is None or hit[0] != tag:
+    if hit is not None and hit[0] != tag and hit[1].device == mods[0].weight.device and hit[1].dtype == mods[0].weight.dtype \
+            and hit[1].shape[0] == sum(m.weight.shape[0] for m in mods) and hit[1].shape[1] == mods[0].weight.shape[1]:
+        # a member changed (load_state_dict / resume): re-concatenate INTO THE SAME BUFFERS — a captured step keeps reading them,
+        # and the in-place copy bumps their version so the derived bf16 / fp32 copies follow (functional.resync_prepared)
+        with torch.no_grad():
+            hit[1].copy_(torch.cat([m.weight.detach() for m in mods], 0))
+            hit[2].copy_(torch.cat([m.bias.detach() for m in mods], 0))
+        hit = (tag, hit[1], hit[2])
+        a.__dict__["_t2v_qkv"] = hit
+    elif hit is None or hit[0] != tag:
         w = torch.nn.Parameter(torch.cat([m.weight.detach() for m in mods], 0).contiguous(), requires_grad=False)
         b = torch.nn.Parameter(torch.cat([m.bias.detach() for m in mods], 0).contiguous(), requires_grad=False)
         hit = (tag, w, b)
         a.__dict__["_t2v_qkv"] = hit
     return hit[1], hit[2]
+
+
+def fused_params(model, refresh=True):
+    """The concatenated q/k/v Parameters `_qkv_fused` keeps in the attention modules' `__dict__` (they are not in
+    `model.parameters()`): the trainer lists them with the frozen parameters whose cached GEMM copies a captured step reads, and
+    calls this before every replay so that re-loaded q/k/v weights reach the fused copy."""
+    out = []
+    if model is None or not supported(model):
+        return out
+    for l in _text_model(model).encoder.layers:
+        a = l.self_attn
+        if "_t2v_qkv" in a.__dict__:
+            hit = _qkv_fused(a) if refresh else a.__dict__["_t2v_qkv"][1:]
+            if hit is not None:
+                out += [hit[0], hit[1]]
+    return out
 
 
 def text_states(model, input_ids):
@@ -86,8 +111,19 @@ def text_states(model, input_ids):
     return x.view(B, S, hidden)
 
 
+_warned = set()
+
+
 def encode(model, input_ids):
-    """What the trainer calls: the native forward where it applies, else the module itself (`model(ids)[0]`)."""
+    """What the trainer calls: the native forward where it applies, else the module itself (`model(ids)[0]`) — with ONE warning per
+    reason: that path runs the vendor GEMM / attention kernels of stock PyTorch-ROCm, not this library's."""
     if _native and input_ids.is_cuda and supported(model):
         return text_states(model, input_ids)
+    why = ("T2V_NATIVE_CLIP=0" if not _native else "token ids on the host" if not input_ids.is_cuda
+           else f"{type(model).__name__}: not a CLIP text tower with head_dim 64 and gelu / quick_gelu")
+    if why not in _warned:
+        _warned.add(why)
+        import warnings
+        warnings.warn(f"t2v_amd: the text encoder runs through its own (stock PyTorch-ROCm) forward, not the native kernels: {why}",
+                      RuntimeWarning, stacklevel=2)
     return model(input_ids)[0]

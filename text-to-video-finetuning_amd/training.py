@@ -507,8 +507,13 @@ class DenoiseTrainer:
         self._replays = 0
         self._pipe = None
         mods = [self.unet, self.vae] + ([self.text_encoder] if self.text_encoder is not None else [])
+        # frozen parameters whose cached copies the graph reads: GEMM-layout bf16 copies (`_t2v_prep`) AND the fp32 copies of bf16
+        # bias / LayerNorm vectors (`_t2v_f32`: CLIP and VAE towers kept in bf16), plus the fused q/k/v copies of the CLIP tower,
+        # which live in the attention modules' __dict__, not in parameters()
+        from .models import clip_text
         self._frozen = [p for m in mods if m is not None for p in m.parameters()
-                        if not p.requires_grad and "_t2v_prep" in p.__dict__]
+                        if not p.requires_grad and ("_t2v_prep" in p.__dict__ or "_t2v_f32" in p.__dict__)]
+        self._frozen += clip_text.fused_params(self.text_encoder, refresh=False)
         if not pipelined:
             self.opt.zero_grad()
             g = torch.cuda.CUDAGraph()
@@ -547,7 +552,9 @@ class DenoiseTrainer:
         if getattr(self.opt, "merge", None) is not None:
             self.opt.merge.sync_base()             # base weights re-loaded since the last step? (masters refresh in place)
         from .functional import resync_prepared
-        resynced = resync_prepared(self._frozen)   # ... and the cached bf16 copies of the unwrapped frozen layers
+        from .models import clip_text
+        clip_text.fused_params(self.text_encoder)  # re-loaded q/k/v weights of the CLIP tower -> its fused copy (in place)
+        resynced = resync_prepared(self._frozen)   # ... and the cached bf16 / fp32 copies of the unwrapped frozen layers
         if self._pipe is None:
             if batch is not None:
                 for k, v in batch.items():
