@@ -106,8 +106,10 @@ def build_models(frames, lora_rank, device, seed, dropout=False, grad_ckpt=False
 
 def build_text_encoder(device):
     """Random-init CLIP text tower in the ModelScope/OpenCLIP ViT-H shape (23 layers, d=1024, 16 heads, MLP 4096, 77 tokens;
-    SURVEY.md A.10), frozen, bf16.  It is adjacent to the hot path (§8f row 2, ~45 GFLOP of a 24 TFLOP step) and runs through
-    stock PyTorch-ROCm ops; it is inside the timed step so that no part of the reference's step is skipped."""
+    SURVEY.md A.10), frozen, bf16.  It is adjacent to the hot path (§8f row 2, ~45 GFLOP of a 24 TFLOP step); since round 4 its
+    forward runs on this library's kernels (t2v_amd/models/clip_text.py: LayerNorm, fused q/k/v on the skinny weight-streaming
+    kernel, causal attention, GELU — only the two embedding gathers are torch index ops); it is inside the timed step so that no
+    part of the reference's step is skipped."""
     try:
         from transformers import CLIPTextConfig, CLIPTextModel
         cfg = CLIPTextConfig(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=23,

@@ -536,7 +536,8 @@ def test_stable_lora_embedding_follows_loralib():
 
 
 def test_lr_schedules_follow_the_reference_options():
-    """train.py:606-612 -> diffusers.get_scheduler: constant / constant_with_warmup / linear / cosine multipliers."""
+    """train.py:606-612 -> diffusers.get_scheduler: all six names (constant, constant_with_warmup, linear, cosine,
+    cosine_with_restarts, polynomial), each against its closed form."""
     import math
     from t2v_amd.training import lr_lambda
     assert [lr_lambda("constant")(k) for k in (0, 10, 10 ** 6)] == [1.0, 1.0, 1.0]
@@ -547,9 +548,23 @@ def test_lr_schedules_follow_the_reference_options():
     f = lr_lambda("cosine", 0, 8)
     assert f(0) == 1.0 and abs(f(4) - 0.5) < 1e-12 and abs(f(8)) < 1e-12
     assert all(f(k) >= f(k + 1) for k in range(8))
+    # diffusers' get_cosine_with_hard_restarts_schedule_with_warmup (num_cycles = 1 by default: the cosine half-wave, ending at 0
+    # instead of clamping; 2 cycles: back to 1.0 at the half-way restart)
+    f = lr_lambda("cosine_with_restarts", 2, 10)
+    assert f(1) == 0.5 and f(2) == 1.0 and abs(f(6) - 0.5) < 1e-12 and f(10) == 0.0 and f(11) == 0.0
+    f2 = lr_lambda("cosine_with_restarts", 0, 8, num_cycles=2)
+    assert f2(0) == 1.0 and abs(f2(2) - 0.5) < 1e-12 and f2(4) == 1.0 and abs(f2(6) - 0.5) < 1e-12 and f2(8) == 0.0
+    # diffusers' get_polynomial_decay_schedule_with_warmup (power 1, lr_end 1e-7): lr(k) = (lr0 - lr_end) (1 - (k-w)/(T-w)) + lr_end
+    f = lr_lambda("polynomial", 2, 10, base_lr=1e-3)
+    assert f(1) == 0.5 and f(2) == 1.0 and abs(f(6) * 1e-3 - ((1e-3 - 1e-7) * 0.5 + 1e-7)) < 1e-15 and abs(f(10) * 1e-3 - 1e-7) < 1e-15
+    assert abs(f(50) * 1e-3 - 1e-7) < 1e-15
     import pytest
     with pytest.raises(ValueError):
         lr_lambda("linear", 2)
+    with pytest.raises(ValueError):
+        lr_lambda("polynomial", 0, 10)                      # needs the optimiser's initial rate
+    with pytest.raises(ValueError):
+        lr_lambda("one_cycle", 0, 10)
 
 
 def test_bucket_sizes_of_the_reference_are_whole_latent_octets():

@@ -63,9 +63,9 @@ def build(force=False, verbose=True):
         if pr.returncode != 0:
             failed = True
             sys.stderr.write(f"--- {src} failed ---\n{out}\n")
-        elif verbose and out.strip():
-            print(out)
         else:
+            if verbose and out.strip():          # warnings: shown, and the object is stamped all the same (it did compile)
+                print(out)
             obj = os.path.join(CSRC, src.replace(".hip", ".o"))
             with open(obj + ".sha256", "w") as f:
                 f.write(stamps[obj])

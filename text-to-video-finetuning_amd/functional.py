@@ -752,7 +752,7 @@ class _LoraLayer(torch.autograd.Function):
         # Epilogue form: dx = dy (*) W^T + s dt (*) D^T in ONE launch — the rank-wide term is a few extra MFMAs per output
         # fragment on operands read straight from memory (dt, the flipped-tap transpose of s D), no pass over dx
         kw = None
-        if (need_dx and not ride and ctx.prep_ok and x.shape[0] == M and
+        if (need_dx and not ride and ctx.prep_ok and x.shape[0] == M and M >= _LORA_EPI_MIN_ROWS_BWD and
                 (not conv or (_wgrad_window_ok(cfg.fwd_geom(cin_p), M) and cfg.taps() in (1, 3, 9)))):
             wb = prepared_weight(w_base, "bwd")
             dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
@@ -813,6 +813,8 @@ class _LoraLayer(torch.autograd.Function):
 _drop_fuse = os.environ.get("T2V_DROP_FUSE", "1") != "0"       # A/B switch: masks regenerated inside the backward kernels
 _lora_epi = os.environ.get("T2V_LORA_EPI", "1") != "0"         # A/B switch: the dropped LoRA branch as an epilogue term of the base launch
 _LORA_EPI_MIN_ROWS = int(os.environ.get("T2V_LORA_EPI_MIN_ROWS", "128"))
+# the same for the backward-data launch (dx = dy (*) W^T + s dt (*) D^T as an epilogue term vs a plain launch + a rank update pass)
+_LORA_EPI_MIN_ROWS_BWD = int(os.environ.get("T2V_LORA_EPI_MIN_ROWS_BWD", "128"))
 
 
 def _lora_side_grads(x, dy_ptr, lddy, keep, cfg, e, scale, M, npad, cin_p, t=None, dt=None, drop=None):
@@ -1086,8 +1088,9 @@ class _LoraGroup(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dys):
-        x, t = ctx.saved_tensors[:2]
-        w_bases = ctx.saved_tensors[2:]
+        saved = ctx.saved_tensors              # ONE access: under torch.utils.checkpoint a second unpack of a recomputed tensor raises
+        x, t = saved[:2]
+        w_bases = saved[2:]
         g, scale = ctx.g, ctx.scale
         n, M = g.n, x.shape[0]
         need_dx = ctx.needs_input_grad[0]
@@ -1158,8 +1161,9 @@ class _LoraGroupDrop(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dys):
-        x, t = ctx.saved_tensors[:2]
-        w_bases = ctx.saved_tensors[2:]
+        saved = ctx.saved_tensors              # ONE access: under torch.utils.checkpoint a second unpack of a recomputed tensor raises
+        x, t = saved[:2]
+        w_bases = saved[2:]
         g, scale = ctx.g, ctx.scale
         drop_p, seeds = ctx.drop
         n, M = g.n, x.shape[0]

@@ -45,17 +45,22 @@ def mse_loss(pred, target):
     return _Mse.apply(pred, target)
 
 
-def lr_lambda(name="constant", num_warmup_steps=0, num_training_steps=None):
+def lr_lambda(name="constant", num_warmup_steps=0, num_training_steps=None, base_lr=None, num_cycles=1, power=1.0, lr_end=1e-7):
     """Multiplier of the base learning rate at optimiser step `k` (0-based) — the schedules `diffusers.get_scheduler` builds for
     the reference's `lr_scheduler` / `lr_warmup_steps` / `max_train_steps` options (train.py:481,519,606-612): "constant"
-    (the default), "constant_with_warmup", "linear", "cosine"."""
+    (the default), "constant_with_warmup", "linear", "cosine", "cosine_with_restarts" (hard restarts, `num_cycles`) and
+    "polynomial" (decay from `base_lr` to `lr_end` with `power`; needs `base_lr`, the optimiser's initial rate).  diffusers is not
+    installable here: the six formulas are restated from its optimization.py and pinned by closed-form tests
+    (tests/test_host_logic.py)."""
     import math
     w, total = int(num_warmup_steps), num_training_steps
-    if name not in ("constant", "constant_with_warmup", "linear", "cosine"):     # (checked when the schedule is BUILT, not mid-training)
-        raise ValueError(f"unknown lr schedule {name!r} (supported: constant, constant_with_warmup, linear, cosine — the ones the "
-                         f"shipped configs use; diffusers' polynomial / cosine_with_restarts are not restated)")
-    if name in ("linear", "cosine") and not total:
+    names = ("constant", "constant_with_warmup", "linear", "cosine", "cosine_with_restarts", "polynomial")
+    if name not in names:                                     # (checked when the schedule is BUILT, not mid-training)
+        raise ValueError(f"unknown lr schedule {name!r} (supported: {', '.join(names)})")
+    if name in ("linear", "cosine", "cosine_with_restarts", "polynomial") and not total:
         raise ValueError(f"lr schedule {name!r} needs num_training_steps")
+    if name == "polynomial" and not (base_lr and base_lr > lr_end):
+        raise ValueError(f"lr schedule 'polynomial' needs base_lr > lr_end ({lr_end}), got {base_lr!r}")
 
     def f(k):
         if name == "constant":
@@ -64,12 +69,19 @@ def lr_lambda(name="constant", num_warmup_steps=0, num_training_steps=None):
             return float(k) / float(max(1, w))
         if name == "constant_with_warmup":
             return 1.0
+        if name == "polynomial":
+            if k > total:
+                return lr_end / base_lr
+            pct = 1.0 - float(k - w) / float(total - w)
+            return ((base_lr - lr_end) * pct ** power + lr_end) / base_lr
         prog = float(k - w) / float(max(1, total - w))
         if name == "linear":
             return max(0.0, 1.0 - prog)
         if name == "cosine":
             return max(0.0, 0.5 * (1.0 + math.cos(math.pi * min(1.0, prog))))
-        raise ValueError(f"unknown lr schedule {name!r}")
+        if prog >= 1.0:                                       # cosine_with_restarts
+            return 0.0
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(num_cycles) * prog) % 1.0))))
     return f
 
 
@@ -111,6 +123,8 @@ class FlatAdamW:
         if model is not None:
             from .models.leaves import assign_dropout_names
             assign_dropout_names(model)          # dropout seeds keyed by module name (models/leaves.py)
+            for name, p in model.named_parameters():
+                p.__dict__.setdefault("_t2v_pname", name)     # (layout fingerprint of state_dict)
         plans = lora_bank.plan(model)
         plist = lora_bank.reorder(plist, plans)
         self.params = plist
@@ -177,20 +191,41 @@ class FlatAdamW:
         if self.prep is not None:
             self.prep.run()
 
+    def _layout_fingerprint(self):
+        """Hash of what the flat buffers MEAN: every trainable tensor's qualified name (where a model was given), shape and slot
+        size in bank order.  Two trainers with equal `numel` but another trainable set / lora_bank plan read different hashes."""
+        import hashlib
+        h = hashlib.sha256()
+        for p, view, _ in self._homes:
+            h.update(f"{p.__dict__.get('_t2v_pname', '?')}|{tuple(p.shape)}|{view.numel()}|{tuple(view.shape)};".encode())
+        return h.hexdigest()[:32]
+
     def state_dict(self):
         """Optimiser state for checkpoint / resume: the AdamW moments in the flat layout of THIS trainer (same model, same trainable
-        set, same lora_bank plan), the device step counter and `steps_done` — the position of the LR schedule, which the reference
-        restores through its scheduler's state (train.py:606-612)."""
-        return {"steps_done": int(self.steps_done), "numel": int(self.numel), "exp_avg": self.exp_avg.detach().clone(),
-                "exp_avg_sq": self.exp_avg_sq.detach().clone(), "step_count": self.step_count.detach().clone()}
+        set, same lora_bank plan — `layout` fingerprints that), the device step counter, `steps_done` — the position of the LR
+        schedule, which the reference restores through its scheduler's state (train.py:606-612) — and the dropout position (base
+        seed + optimisation step of the host protocol, models/leaves.py), so that a resumed run does not redraw the masks of
+        steps 0..k."""
+        from .models import leaves
+        return {"steps_done": int(self.steps_done), "numel": int(self.numel), "layout": self._layout_fingerprint(),
+                "exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
+                "step_count": self.step_count.detach().clone(),
+                "dropout": {"base": int(leaves._seed_state["base"]), "step": int(leaves._seed_state["step"])}}
 
     def load_state_dict(self, sd):
         if int(sd["numel"]) != int(self.numel):
             raise RuntimeError(f"t2v_amd: optimiser state of {sd['numel']} elements does not fit this trainer ({self.numel})")
+        if "layout" in sd and sd["layout"] != self._layout_fingerprint():
+            raise RuntimeError("t2v_amd: optimiser state was saved for another trainable set / LoRA bank layout (same element count, "
+                               "different tensors): its moments would be applied to the wrong parameters")
         self.steps_done = int(sd["steps_done"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count.copy_(sd["step_count"])
+        if "dropout" in sd:
+            from .models import leaves
+            leaves._seed_state["base"], leaves._seed_state["step"] = int(sd["dropout"]["base"]), int(sd["dropout"]["step"])
+            leaves._seed_state["fwd"] = -1
 
     def zero_grad(self, set_to_none=False):
         from .functional import clear_bwd_colsums, drop_pending_wgrads
@@ -263,7 +298,7 @@ class DenoiseTrainer:
             self.scheduler.rescale_betas()         # train.py:689-690 (betas only; see schedulers.enforce_zero_terminal_snr)
         self.opt = FlatAdamW(params, lr, betas, weight_decay, eps, max_grad_norm, model=unet, world_size=1)   # (exchange: below)
         if lr_scheduler != "constant":      # train.py:606-612
-            self.opt.lr_schedule = lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps)
+            self.opt.lr_schedule = lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps, base_lr=lr)
         self.gas = max(1, int(gradient_accumulation_steps))      # train.py:481,519,848 (`accelerator.accumulate`)
         self._micro = 0
         self.pg, self.world = process_group, world_size
@@ -443,6 +478,23 @@ class DenoiseTrainer:
         """Raise if a kernel of an earlier step flagged a device-side failure (split-K hand-off time-out).  Synchronises."""
         from .functional import check_gemm_workspaces
         check_gemm_workspaces()
+
+    def state_dict(self):
+        """Everything a resumed run needs beyond the parameters themselves (which the reference saves through its pipeline /
+        LoRA files, train.py:911-935): the optimiser state (moments, step counter, LR-schedule position, dropout step) and the
+        device-side dropout epoch of this trainer's captured / eager steps."""
+        self.check_device_flags()          # a checkpoint is a natural sync point: no split-K hand-off gave up since the last one
+        ep = None if self._drop_epoch is None else int(self._drop_epoch.item())
+        return {"opt": self.opt.state_dict(), "drop_epoch": ep, "micro": int(self._micro)}
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd["opt"])
+        if sd.get("drop_epoch") is not None:
+            if self._drop_epoch is None:
+                self._drop_epoch = torch.zeros(1, dtype=torch.int64, device=self.opt.flat_p.device)
+            self._drop_epoch.fill_(int(sd["drop_epoch"]))       # in place: a captured step reads this address
+        self._micro = int(sd.get("micro", 0))
+        self.opt.refresh_bf16()
 
     # ---- HIP-graph replay of forward+backward (static shapes)
     def capture(self, batch, warmup=2, pipelined=None):
