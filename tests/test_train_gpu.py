@@ -607,7 +607,9 @@ def test_trainer_state_round_trip_resumes_the_same_trajectory():
     l3b = t2.train_step(batches[2]).item()
     torch.cuda.synchronize()
     print(f"step 3: uninterrupted {l3:.7f} resumed {l3b:.7f}; max parameter difference {(t2.opt.flat_p - p3).abs().max().item():.3e}")
-    assert l3b == l3 and torch.equal(t2.opt.flat_p, p3)
+    # the loss is bit-equal (same masks, same parameters in); the UPDATED parameters agree to the last ulp or two: the factor-gradient
+    # sums of one backward pass are fp32 atomics (lora_wgrad.hip), whose order differs run to run (measured 6e-8)
+    assert l3b == l3 and (t2.opt.flat_p - p3).abs().max().item() <= 1e-6
     bad = dict(sd["opt"]); bad["layout"] = "0" * 32
     with pytest.raises(RuntimeError, match="another trainable set"):
         t2.opt.load_state_dict(bad)

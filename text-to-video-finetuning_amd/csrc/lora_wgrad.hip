@@ -165,15 +165,20 @@ __device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, lon
 // copy of dy is ever written (round 3: a mask pass (read + write) plus a skinny GEMM (read) = three passes and two launches).
 // v_mfma_f32_16x16x32_bf16 with A = 16 rows x 32 columns of dy, B = the same 32 columns of 16 rank rows of U; the contraction
 // index is permuted so that a lane reads 2 x 16 contiguous bytes of its row (k group g <-> columns 16g .. 16g+15 of a 64-column
-// block, MFMA step s takes the s-th 8).  Workgroup = 4 waves as WR x WC: a wave owns 32 rows (two row groups) and every WC-th
-// 64-column block; with WC > 1 the partial sums meet in LDS.
-template <int RG>      // rank groups of 16
-__global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ U,
-                                                            long long ldu, bf16_t* __restrict__ dt, long long lddt, long long M, int N,
-                                                            int rp, int WC, float p, unsigned long long seed_in,
-                                                            const unsigned long long* __restrict__ epoch, long long u_member_stride,
-                                                            unsigned long long seed1, unsigned long long seed2) {
-  __shared__ float red[4][32][RG * 16 + 1];
+// block, MFMA step s takes the s-th 8).
+// Round 5 shape of the launch (profiles/r05_branch_probe.txt: the round-4 kernel ran 364 launches of a C2 step at 0.1 - 3.2 TB/s,
+// ~12 us whatever the size below M = 8192 — 16 .. 64 workgroups of 4 waves with two dependent load rounds each): a workgroup is
+// NW = 4 .. 16 waves laid out WR x WC, a wave owns ROWG row groups of 16 rows and every WC-th 64-column block with UNR blocks in
+// flight; the launcher picks (ROWG, WC, NW) so that >= ~2048 waves are in flight and a wave needs ONE load round where the
+// column count allows (N = 320: UNR = 5).  With WC > 1 the partial sums meet in LDS, added in wave order (bit-reproducible).
+template <int RG, int ROWG, int UNR, int MAXT>      // rank groups of 16, row groups per wave, 64-column blocks in flight per wave, block size bound
+__global__ __launch_bounds__(MAXT) void lora_drop_dt_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ U,
+                                                             long long ldu, bf16_t* __restrict__ dt, long long lddt, long long M, int N,
+                                                             int rp, int WC, float p, unsigned long long seed_in,
+                                                             const unsigned long long* __restrict__ epoch, long long u_member_stride,
+                                                             unsigned long long seed1, unsigned long long seed2) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];     // [NW][ROWG*16][RG*16 + 1] (WC > 1 only)
+  constexpr int RPW = ROWG * 16, PITCH_R = RG * 16 + 1;
   // projection group: blockIdx.y = member (own column block of dy, own up factor, own seed, own rank columns of dt)
   if (blockIdx.y > 0) {
     dy += (long long)blockIdx.y * N;
@@ -182,21 +187,21 @@ __global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restr
     seed_in = blockIdx.y == 1 ? seed1 : seed2;
   }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int WR = 4 / WC, wr = w / WC, wc = w - wr * WC;
+  const int NW = (int)blockDim.x >> 6;
+  const int WR = NW / WC, wr = w / WC, wc = w - wr * WC;
   const int li = lane & 15, g4 = lane >> 4;
-  const long long row0 = ((long long)blockIdx.x * WR + wr) * 32;
+  const long long row0 = ((long long)blockIdx.x * WR + wr) * RPW;
   const DropKey dkey = drop_key(eff_seed(seed_in, epoch), p);
   const float ks = 1.f / (1.f - p);
-  f32x4 acc[2][RG];
+  f32x4 acc[ROWG][RG];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < ROWG; ++a)
 #pragma unroll
     for (int j = 0; j < RG; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const int nblk = (N + 63) >> 6;
-  constexpr int UNR = RG == 1 ? 4 : 2;             // 64-column blocks in flight per wave (N = 320 on two wave columns: one round trip)
   for (int b0 = wc; b0 < nblk; b0 += WC * UNR) {
-    bf16x8 a[UNR][2][2], u[UNR][RG][2];
+    bf16x8 a[UNR][ROWG][2], u[UNR][RG][2];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
       const int col = (b0 + q * WC) * 64 + g4 * 16;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restr
       for (int s = 0; s < 2; ++s) {
         const bool cok = (b0 + q * WC) < nblk && col + s * 8 < N;
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
+        for (int rg = 0; rg < ROWG; ++rg) {
           const long long row = row0 + rg * 16 + li;
           a[q][rg][s] = (cok && row < M) ? *(const bf16x8*)(dy + row * lddy + col + s * 8) : zero8;
         }
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restr
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
+        for (int rg = 0; rg < ROWG; ++rg) {
           const long long row = row0 + rg * 16 + li;
           bf16x8 g = a[q][rg][s];
           if (row < M && col + s * 8 < N) {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restr
   // accumulator: lane holds rows 4*g4 + r (r = 0..3) of the row group, rank 16j + li
   if (WC == 1) {
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
+    for (int rg = 0; rg < ROWG; ++rg)
 #pragma unroll
       for (int j = 0; j < RG; ++j)
 #pragma unroll
@@ -250,19 +255,20 @@ __global__ __launch_bounds__(256) void lora_drop_dt_kernel(const bf16_t* __restr
         }
     return;
   }
+  float* red = red_dyn + (long long)w * RPW * PITCH_R;
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg)
+  for (int rg = 0; rg < ROWG; ++rg)
 #pragma unroll
     for (int j = 0; j < RG; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][rg * 16 + 4 * g4 + r][j * 16 + li] = acc[rg][j][r];
+      for (int r = 0; r < 4; ++r) red[(rg * 16 + 4 * g4 + r) * PITCH_R + j * 16 + li] = acc[rg][j][r];
   __syncthreads();
-  // WR row bands of 32 rows x (RG*16) ranks, each summed over its WC waves in wave order
-  for (int i = tid; i < WR * 32 * RG * 16; i += 256) {
-    const int rk = i % (RG * 16), rr = (i / (RG * 16)) % 32, band = i / (RG * 16 * 32);
+  // WR row bands of RPW rows x (RG*16) ranks, each summed over its WC waves in wave order
+  for (int i = tid; i < WR * RPW * RG * 16; i += (int)blockDim.x) {
+    const int rk = i % (RG * 16), rr = (i / (RG * 16)) % RPW, band = i / (RG * 16 * RPW);
     float v = 0.f;
-    for (int c = 0; c < WC; ++c) v += red[band * WC + c][rr][rk];
-    const long long row = ((long long)blockIdx.x * WR + band) * 32 + rr;
+    for (int c = 0; c < WC; ++c) v += red_dyn[((long long)(band * WC + c) * RPW + rr) * PITCH_R + rk];
+    const long long row = ((long long)blockIdx.x * WR + band) * RPW + rr;
     if (row < M && rk < rp) dt[row * lddt + rk] = f2bf(v * ks);
   }
 }
@@ -419,32 +425,56 @@ static int lora_drop_dt_launch(const void* dy, long long lddy, const void* U, lo
   T2V_CHECK_ARG(rp >= 8 && rp <= 32 && rp % 8 == 0, "t2v_lora_drop_dt: padded rank must be 8, 16, 24 or 32 (got %d)", rp);
   T2V_CHECK_ARG(nmem >= 1 && nmem <= 3 && seeds, "t2v_lora_drop_dt: 1..3 members");
   T2V_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "t2v_lora_drop_dt: dropout probability must be in [0, 1)");
-  // waves as WR x WC: split the columns over WC waves when the rows alone give too few workgroups, prefer the split that wastes
-  // the fewest 64-column blocks
+  // launch shape: ROWG = 1 (16 rows per wave) until the rows alone give ~4096 waves; columns split over WC waves (1 .. 16, never
+  // more than the 64-column blocks) until ~2048 waves are in flight; a workgroup = max(4, WC) waves (WR x WC)
   const int nblk = (N + 63) / 64;
-  int best_wc = 1;
-  double best = 1e30;
-  for (int wc : {1, 2, 4}) {
-    const long long blocks = (M + 32 * (4 / wc) - 1) / (32 * (4 / wc)) * nmem;
-    const int per = (nblk + wc - 1) / wc;
-    const double waste = (double)per * wc / nblk;
-    const double fill = blocks >= 512 ? 1.0 : 512.0 / (double)blocks;       // under-filled launches: time ~ 1 / blocks
-    const double cost = waste * fill * (wc > 1 ? 1.05 : 1.0);
-    if (cost < best) {
-      best = cost;
-      best_wc = wc;
-    }
-  }
-  const int WR = 4 / best_wc;
-  const long long blocks = (M + 32 * WR - 1) / (32 * WR);
+  const int rowg = (M / 32) * nmem >= 4096 ? 2 : 1;
+  const long long wrows = (M + 16 * rowg - 1) / (16 * rowg) * nmem;
+  int wc = 1;
+  while (wc < 16 && wc * 2 <= nblk && wrows * wc < 2048) wc *= 2;
+  static const int force_wc = [] { const char* e = getenv("T2V_DT_WC"); return e ? atoi(e) : 0; }();          // A/B switches
+  static const int force_rowg = [] { const char* e = getenv("T2V_DT_ROWG"); return e ? atoi(e) : 0; }();
+  if (force_wc == 1 || force_wc == 2 || force_wc == 4 || force_wc == 8 || force_wc == 16) wc = force_wc;
+  const int ROWG = wc > 4 ? 1 : ((force_rowg == 1 || force_rowg == 2) ? force_rowg : rowg);
+  const int NW = wc > 4 ? wc : 4, WR = NW / wc;
+  const long long blocks = (M + 16LL * ROWG * WR - 1) / (16LL * ROWG * WR);
   T2V_CHECK_ARG(blocks < (1LL << 31), "t2v_lora_drop_dt: too many rows");
   const unsigned long long s0 = seeds[0], s1 = nmem > 1 ? seeds[1] : 0ull, s2 = nmem > 2 ? seeds[2] : 0ull;
-  if (rp <= 16)
-    T2V_LAUNCH(lora_drop_dt_kernel<1>, dim3((unsigned)blocks, (unsigned)nmem), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
-               (const bf16_t*)U, ldu, (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, s0, t2v_drop_epoch, u_member_stride, s1, s2);
-  else
-    T2V_LAUNCH(lora_drop_dt_kernel<2>, dim3((unsigned)blocks, (unsigned)nmem), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
-               (const bf16_t*)U, ldu, (bf16_t*)dt, lddt, M, N, rp, best_wc, drop_p, s0, t2v_drop_epoch, u_member_stride, s1, s2);
+  const int RGn = rp <= 16 ? 1 : 2;
+  const size_t lds = wc > 1 ? (size_t)NW * ROWG * 16 * (RGn * 16 + 1) * sizeof(float) : 0;
+  const dim3 grid((unsigned)blocks, (unsigned)nmem), block((unsigned)NW * 64);
+#define T2V_DT_ARGS grid, block, lds, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)U, ldu, (bf16_t*)dt, lddt, M, N, rp, wc, drop_p, s0, \
+                    t2v_drop_epoch, u_member_stride, s1, s2
+  // (workgroups of more than 4 waves are compiled for 1024 threads = 128 registers per lane: ROWG = 1 only, which is what the
+  //  shape rule above gives them — the rows of such launches are few)
+#define T2V_DT_LAUNCH(RG_, ROWG_, UNR_)                                                                   \
+  do {                                                                                                    \
+    if (NW == 4) t2v_launch_timed(3, lora_drop_dt_kernel<RG_, ROWG_, UNR_, 256>, T2V_DT_ARGS);            \
+    else t2v_launch_timed(3, lora_drop_dt_kernel<RG_, 1, UNR_, 1024>, T2V_DT_ARGS);                      \
+  } while (0)
+  // blocks in flight per wave: all of a wave's share when it is <= 5 (N = 320 on one wave column: one load round), else 4 / 3
+  const int per = (nblk + wc - 1) / wc;
+  if (RGn == 1) {
+    if (ROWG == 1) {
+      if (per == 5) T2V_DT_LAUNCH(1, 1, 5);
+      else if (per <= 2) T2V_DT_LAUNCH(1, 1, 2);
+      else T2V_DT_LAUNCH(1, 1, 4);
+    } else {
+      if (per == 5) T2V_DT_LAUNCH(1, 2, 5);
+      else if (per <= 2) T2V_DT_LAUNCH(1, 2, 2);
+      else T2V_DT_LAUNCH(1, 2, 4);
+    }
+  } else {
+    if (ROWG == 1) {
+      if (per <= 2) T2V_DT_LAUNCH(2, 1, 2);
+      else T2V_DT_LAUNCH(2, 1, 3);
+    } else {
+      if (per <= 2) T2V_DT_LAUNCH(2, 2, 2);
+      else T2V_DT_LAUNCH(2, 2, 3);
+    }
+  }
+#undef T2V_DT_LAUNCH
+#undef T2V_DT_ARGS
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

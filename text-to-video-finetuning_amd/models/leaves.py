@@ -99,6 +99,19 @@ def _seed_for(mod, suffix=""):
     return (_seed_state["base"] * 1000003 + key * 97 + _seed_state["step"] * 7919 + max(0, _seed_state["fwd"]) * 104729) & 0xFFFFFFFFFFFF
 
 
+def _low_rank_product(B, A):
+    """`lora_B @ lora_A` of a loralib / stable_lora layer (stable_lora/lora.py:119-126,190-197) on THIS library's GEMM: the rows of
+    B are the activation operand, A^T the weight, so autograd reaches both factors through the same kernels as every other layer
+    (dB = d(delta) A^T by the backward-data launch, dA by the K-major weight-gradient launch) — round 4 formed it with torch.matmul,
+    i.e. a vendor GEMM on a path row.  bf16 operands, fp32 accumulation; the sum W + s delta is rounded to bf16 for the layer's own
+    launch anyway."""
+    r, rp = A.shape[0], F.ceil8(A.shape[0])
+    Bb = B.to(BF16)
+    if rp != r:
+        Bb = torch.nn.functional.pad(Bb, (0, rp - r))
+    return F.conv_linear(Bb.contiguous(), A.t(), None, LINEAR)[:, : A.shape[1]].float()
+
+
 def _drop_p(mod):
     return float(mod.p) if (isinstance(mod, nn.Dropout) and mod.training) else 0.0
 
@@ -150,7 +163,7 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
             t = F.conv_linear(F.dropout(x, p, _seed_for(mod, ".lora_dropout")), mod.lora_A, None, LINEAR)
             return F.conv_linear(t, mod.lora_B, None, LINEAR, None, y, alpha=float(mod.scaling))
         if getattr(mod, "r", 0) > 0 and not getattr(mod, "merged", False):
-            delta = (mod.lora_B @ mod.lora_A)
+            delta = _low_rank_product(mod.lora_B, mod.lora_A)
             if w.dim() == 5:   # stable_lora Conv3d: view(out,in,k,k,1).mean(-2)  (stable_lora/lora.py:148-149,194)
                 delta = delta.view(w.shape[0], w.shape[1], w.shape[2], w.shape[2], 1).mean(dim=-2, keepdim=True) \
                     .view(w.shape)

@@ -529,7 +529,7 @@ class DenoiseTrainer:
         80.5 (host 1; the small CLIP kernels slip in beside the UNet's — the large kernels of two streams do not overlap, each
         fills the CUs: sum of kernel durations = step time in the trace)."""
         if pipelined is None:
-            pipelined = os.environ.get("T2V_GRAPH_PIPELINE", "0") == "1"
+            pipelined = os.environ.get("T2V_GRAPH_PIPELINE", "1") == "1" and os.environ.get("T2V_GRAPH_FORK", "0") != "1"
         self._inline_aux = not pipelined and os.environ.get("T2V_GRAPH_FORK", "0") != "1"
         try:
             return self._capture(batch, warmup, pipelined)
