@@ -11,7 +11,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$root/gpurun_out/${tag}_$c
-  rocprofv3 --kernel-trace --pmc $c -d $out -o pmc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-default-mode --no-host-timing > $out.log 2>&1
+  timeout 480 rocprofv3 --kernel-trace --pmc $c -d $out -o pmc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-default-mode --no-host-timing > $out.log 2>&1
   ms=$(grep '^{"metric"' $out.log | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
   db=$(find $out -name '*.db' | head -1)
   # the last 3 steps of the trace = the timed graph replays (window = 3 x the step time the profiled run itself measured)
