@@ -549,6 +549,23 @@ def cpu_baseline(steps, device, c2_once=True):
                              "against committed oracle fixtures: tests/test_lora_grads_gpu.py")
 
 
+def _dist_info(world):
+    """Backend, collective-library version and the world size `torch.distributed` itself reports (N > 1 lines)."""
+    info = {"world_size_env": world, "initialized": False}
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            info.update(initialized=True, backend=dist.get_backend(), world_size=dist.get_world_size(), rank=dist.get_rank())
+            if dist.get_backend() == "nccl":
+                v = torch.cuda.nccl.version()
+                info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        info["exchange"] = ("one all_reduce(SUM) of the flat fp32 gradient buffer per optimiser step (tail slot = the loss), "
+                            "stream-ordered behind the step graph" if world > 1 else "none (one GPU)")
+    except Exception as e:   # noqa: BLE001
+        info["error"] = f"{type(e).__name__}: {e}"
+    return info
+
+
 def _self_spawn(args):
     """`python bench.py --gpus N` without a torchrun environment: re-launch under torch.distributed.run, one rank per GPU."""
     import socket
@@ -735,7 +752,9 @@ def main():
                                     "restated in oracle/dropout.py); eval_train_ms_per_step = the same clip with every Dropout off "
                                     "(train.py:779-781 opt-in), 10 graph replays" if args.dropout else
                                     "--eval-train line; default_mode_ms_per_step = the same clip in the reference's default mode, 10 graph replays",
-                       "host_ms_per_step": host_ms},
+                       "host_ms_per_step": host_ms,
+                       # what the exchange ran on: lets an N > 1 line be audited
+                       "dist": _dist_info(world)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

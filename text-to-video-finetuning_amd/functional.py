@@ -1205,12 +1205,33 @@ class _LoraGroupDrop(torch.autograd.Function):
 
 
 def lora_group_drop_ok(x, group, scale):
-    """True if the grouped epilogue form applies: transposed factor copies current, batched wgrad path, a descriptor the LR
-    kernels take."""
+    """True if the grouped epilogue form applies: transposed factor copies current, batched wgrad path, and BOTH descriptors it
+    launches — forward (lr_mode 2 with lr_group_cols) and backward-data (lr_mode 1 with all members' ranks side by side) — are
+    ones the library's LR kernels take (`t2v_gemm_lr_ok` on dummy-pointer descriptors of the real shapes: the answer is cached
+    per shape, so a shape the kernels refuse falls back to per-member layers here instead of raising mid-backward)."""
     if not (_lora_epi and _drop_fuse and _wq["enabled"] and getattr(group, "prep_scale", None) == float(scale)):
         return False
-    K = group.cin_p
-    return K % 64 == 0 and group.npad_each % 64 == 0 and x.shape[0] >= _LORA_EPI_MIN_ROWS and x.shape[0] * max(group.npad, K) * 2 < 0x7ff00000
+    M, K = x.shape[0], group.cin_p
+    if M < _LORA_EPI_MIN_ROWS:
+        return False
+    key = (M, K, group.npad, group.npad_each, group.rp, group.rp_each, group.rk, _ld(group.down_t16))
+    hit = _group_ok_cache.get(key)
+    if hit is None:
+        p16 = 16                                    # (aligned dummy addresses: t2v_gemm_lr_ok reads the descriptor only)
+        fwd = dict(M=M, N=group.npad, K=K, A=p16, lda=K, B=p16, ldb=K, D=p16, ldd=group.npad, B2=p16, ldb2=K, D2=p16, ldd2=group.rp,
+                   lr=dict(mode=2, rp=group.rp_each, b=p16, ldb=group.rk, scale=float(scale), drop_p=0.1, drop_seed=1,
+                           group_cols=group.npad_each, group_seeds=(2, 3)[: max(0, group.n - 1)]))
+        bwd = dict(M=M, N=K, K=group.npad, A=p16, lda=group.npad, B=p16, ldb=group.npad, D=p16, ldd=K,
+                   lr=dict(mode=1, rp=group.rp, taps=1, a=p16, lda=group.rp, b=p16, ldb=_ld(group.down_t16)))
+        try:
+            hit = _lr_ok(fwd) and _lr_ok(bwd)
+        except Exception:   # noqa: BLE001  (a descriptor make_gemm itself refuses)
+            hit = False
+        _group_ok_cache[key] = hit
+    return hit
+
+
+_group_ok_cache = {}
 
 
 def lora_group_drop(x, group, scale, w_bases, drop_p, seeds):

@@ -507,24 +507,22 @@ class DenoiseTrainer:
         drained — while a single-stream graph is submitted as pre-built packets in under 1 ms without waiting, so the host runs
         steps ahead of the device (what the data-parallel exchange and a Python training loop around the step need).
 
-        pipelined=False (default): ONE graph on ONE stream — the frozen CLIP tower and the parameter refresh, which the eager step
-        forks onto the auxiliary stream, stay on the launch stream while the capture is open.  T2V_GRAPH_FORK=1 restores round
-        3's forked single graph.
-        pipelined=True (T2V_GRAPH_PIPELINE=1; experimental): the step as TWO single-stream graphs, twice over —
+        pipelined=False: ONE graph on ONE stream — the frozen CLIP tower and the parameter refresh, which the eager step forks onto
+        the auxiliary stream, stay on the launch stream while the capture is open.  T2V_GRAPH_FORK=1 restores round 3's forked
+        single graph.
+        pipelined=True (the default since round 5; T2V_GRAPH_PIPELINE=0 / pipelined=False = the one-graph form): the step as TWO
+        single-stream graphs, twice over —
           P_k  `_prepare`: frozen CLIP tower, VAE encode, noise, timesteps, add_noise -> prepared batch k     (k = 0, 1)
           U_k  `_fwd_bwd` on prepared batch k: parameter refresh, UNet forward + backward, factor gradients
         with step i replaying P_{i%2} on the auxiliary stream (as soon as U of step i-2 has released the slot, i.e. beside U of
         step i-1) and U_{i%2} on the launch stream.  The two kinds of graph may run concurrently and therefore record into
         separate memory pools and on separate streams (GEMM / GroupNorm scratch is per stream); the two copies of one kind are
-        serialised by stream order.  Not the default: it was measured with the two P graphs sharing one memory pool, and with P
-        truly running beside U (host inputs, or the captured batch again) step 3 of six sat 3e-3 off the eager loss in every run
-        of tests/test_train_gpu.py::test_pipelined_replays_without_host_sync_follow_the_eager_trajectory[True].  The likely cause,
-        found after the round's GPU time was spent: slot 1's prepared batch was allocated during the second capture on blocks
-        the first P graph had used for intermediates, so P of step 4 (slot 0) wrote over the batch U of step 3 was reading (only
-        an odd step with a successor and a host that is already running ahead shows it — exactly step 3 of six).  Every P graph
-        now records into its own pool; until that is confirmed on hardware the form stays opt-in.  A second lesson from the same
-        test: a replay right behind an asynchronous host-to-device copy started before the copy had landed (host inputs now go
-        up through a temporary + copy kernel).
+        serialised by stream order.  Every P graph records into a pool of its OWN: round 4 measured the form with both P graphs
+        in one pool, where slot 1's prepared batch sat on blocks the other P graph uses for intermediates (P of step 4 wrote over
+        the batch U of step 3 was reading: 3e-3 on that step, 5 runs of 5); with separate pools the host-batch and device-batch
+        runs of tests/test_train_gpu.py::test_pipelined_replays_without_host_sync_follow_the_eager_trajectory replay identical
+        losses (profiles/r05_pytest_first_run.log).  A second lesson from the same test: a replay right behind an asynchronous
+        host-to-device copy started before the copy had landed (host inputs go up through a temporary + copy kernel).
         Same box, ms per step (profiles/r04_capture_modes.txt): forked 80.4 (host 74 per step), one stream 81.4 (host 1), pipelined
         80.5 (host 1; the small CLIP kernels slip in beside the UNet's — the large kernels of two streams do not overlap, each
         fills the CUs: sum of kernel durations = step time in the trace)."""
