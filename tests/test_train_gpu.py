@@ -235,7 +235,9 @@ def test_cached_latents_path_equals_encode_path():
         l_cached = tr.loss_fn(cached)
         l_cached2 = tr.loss_fn(dict(batch, pixel_values=lat))
     print(f"loss: in-step encode {l_enc.item():.7f}  cached (same latents) {l_cached.item():.7f}  cached (re-encoded) {l_cached2.item():.7f}")
-    assert torch.equal(l_enc, l_cached)                     # same latents in -> the very same step
+    # same latents in -> the very same step: equal up to the order of the fp32 atomics of the loss reduction (the eps-MSE kernel sums
+    # per-workgroup partials with atomicAdd: two evaluations of the same tensors differ in the last bit or two — measured 0 .. 1e-7)
+    assert abs(l_cached.item() - l_enc.item()) <= 2e-6 * abs(l_enc.item())
     assert abs(l_cached2.item() - l_enc.item()) <= 1e-4 * abs(l_enc.item())
 
 
@@ -607,9 +609,10 @@ def test_trainer_state_round_trip_resumes_the_same_trajectory():
     l3b = t2.train_step(batches[2]).item()
     torch.cuda.synchronize()
     print(f"step 3: uninterrupted {l3:.7f} resumed {l3b:.7f}; max parameter difference {(t2.opt.flat_p - p3).abs().max().item():.3e}")
-    # the loss is bit-equal (same masks, same parameters in); the UPDATED parameters agree to the last ulp or two: the factor-gradient
-    # sums of one backward pass are fp32 atomics (lora_wgrad.hip), whose order differs run to run (measured 6e-8)
-    assert l3b == l3 and (t2.opt.flat_p - p3).abs().max().item() <= 1e-6
+    # the loss agrees to the order of its own fp32 atomics (same masks, same parameters in: measured 0 and 1e-7 in two runs — a run
+    # with other masks or cold moments differs in the third digit); the UPDATED parameters agree to the last ulp or two: the
+    # factor-gradient sums of a backward pass are fp32 atomics too (lora_wgrad.hip; measured 3e-8 .. 6e-8)
+    assert abs(l3b - l3) <= 2e-6 * abs(l3) and (t2.opt.flat_p - p3).abs().max().item() <= 1e-6
     bad = dict(sd["opt"]); bad["layout"] = "0" * 32
     with pytest.raises(RuntimeError, match="another trainable set"):
         t2.opt.load_state_dict(bad)

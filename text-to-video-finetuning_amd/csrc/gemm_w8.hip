@@ -271,6 +271,23 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     advance_window();
   };
 
+  // Round 5: the tile's bias goes to LDS by ONE LDS-DMA instruction of the first BN/4 threads, ahead of the ring prologue (an
+  // older entry of the same counter: the prologue's counted waits cover it), into BN floats behind the ring and the split-K flag.
+  // The register epilogue used to fetch every 8-column chunk's bias (and row bias / residual) from memory one chunk ahead of its
+  // use behind divergent guards, and the compiler answered with `s_waitcnt vmcnt(0)` in every chunk — one exposed memory round
+  // trip per chunk, 6-12 per wave (profiles/r03_w8_timeline.txt prices that epilogue at 11 000-18 000 cycles).  Reading the bias
+  // from LDS costs no vector-memory wait at all and, unlike starting the accumulators at the bias, no register in the K loop (the
+  // 128x384 kernels sit at the 256-register allocation: that variant spilled loader state into the loop).  Columns outside the
+  // tile / in the rank block read an out-of-range offset: the hardware writes zeros.
+  constexpr int BIAS_OFF = SMEM_BYTES + 16;
+  const bool bias_lds = !CS && p.bias != nullptr;
+  if (bias_lds && tid < BN / 4) {
+    __amdgpu_buffer_rsrc_t srdBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, 0x80000000u, 0x00020000);
+    const int tc = tid * 4;
+    const bool cok = tc < nbase && !(p.n_split > 0 && n0 + tc >= p.n_split);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srdBias, (__attribute__((address_space(3))) void*)(smem + BIAS_OFF + tid * 16), 16,
+                                             cok ? (n0 + tc) * 4 : (int)0x80000000u, 0, 0, 0);
+  }
   // the ring's first stages go out BEFORE the rest of the set-up (accumulators, fragment addressing): their memory latency
   // is the longest item in front of the first MFMA
   constexpr int NPRO = (SCHED == 0 || SCHED == 4) ? NSTAGE - 1 : NSTAGE;
@@ -613,6 +630,8 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   // staged in LDS by all 512 threads — three barriers and index arithmetic cost more than the round trips they save.
   auto rank_phase = [&](int ib0_, auto nb_tag) {
     constexpr int NB = decltype(nb_tag)::value;
+    constexpr int JB = (KG == 2 && FN >= 3) ? 3 : (FN < 2 ? FN : 2);      // column fragments whose LB loads share one round trip (the
+                                                                           // 128x384 kernels spill in this phase with more than two)
     const int half = lane >> 5, l31 = lane & 31;
     const int rp = p.lr_rp, nk = (rp + 15) >> 4, rkp = nk * 16;        // (nk <= 2 in mode 2, <= 3 in mode 1: launch_w8)
     const bool masked = p.lr_drop_p > 0.f;
@@ -624,7 +643,6 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     const bool direct = !masked && sc == 1.f;
     const bf16_t* LB = (const bf16_t*)p.lr_b;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bf16x4 zero4 = {0, 0, 0, 0};
     bf16x8 la[NB][3];
     unsigned rowg[NB];
 #pragma unroll
@@ -680,26 +698,39 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) la[io][ks] = ks < nk ? xt[((wr * FM + ib0_ + io) * 2 + ks) * 64 + lane] : zero8;
       __syncthreads();                               // (the staging passes reuse this LDS)
+      // the U fragments of ALL column fragments in one batch (round 5: fragment by fragment the compiler waited vmcnt(0) in front
+      // of every fragment's MFMAs — FN exposed round trips; columns beyond the tile read row n0 of lr_b: their products are
+      // never stored)
+      // (batches of JB <= 3 fragments: the 128x384 kernels have no registers for all six)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        if (col0_of(j) >= nbase) continue;           // rank fragment, padding
-        const bool cok = col0_of(j) + l31 < nbase;
-        const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + 4 * half;
-        bf16x8 lb[2];
+      for (int j0 = 0; j0 < FN; j0 += JB) {
+        bf16x8 lbv[JB][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x4 lo = (cok && ks < nk) ? *(const bf16x4*)(lbp + 16 * ks) : zero4;
-          const bf16x4 hi = (cok && ks < nk) ? *(const bf16x4*)(lbp + 16 * ks + 8) : zero4;
-          lb[ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int jj = 0; jj < JB; ++jj) {
+          const int j = j0 + jj;
+          if (j >= FN || col0_of(j) >= nbase) continue;           // rank fragment, padding
+          const bool cok = col0_of(j) + l31 < nbase;
+          const bf16_t* lbp = LB + (unsigned)(n0 + (cok ? col0_of(j) + l31 : 0)) * (unsigned)p.lr_ldb + 4 * half;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nk) continue;
+            const bf16x4 lo = *(const bf16x4*)(lbp + 16 * ks), hi = *(const bf16x4*)(lbp + 16 * ks + 8);
+            lbv[jj][ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
         }
 #pragma unroll
-        for (int io = 0; io < NB; ++io) {
-          f32x16 tmp;
+        for (int jj = 0; jj < JB; ++jj) {
+          const int j = j0 + jj;
+          if (j >= FN || col0_of(j) >= nbase) continue;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
-          tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], tmp, 0, 0, 0);
-          if (nk > 1) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], tmp, 0, 0, 0);
-          finish(io, j, tmp);
+          for (int io = 0; io < NB; ++io) {
+            f32x16 tmp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+            tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][0], la[io][0], tmp, 0, 0, 0);
+            if (nk > 1) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][1], la[io][1], tmp, 0, 0, 0);
+            finish(io, j, tmp);
+          }
         }
       }
       return;
@@ -735,44 +766,60 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           la[io][ks] = (v && ks < nk && 16 * ks + 8 * half < rp) ? *(const bf16x8*)(LA + src * (unsigned)p.lr_lda + 16 * ks + 8 * half) : zero8;
       }
     };
-    auto load_lb = [&](int j, int tap, bf16x8(&lb)[3]) {
-      const bool cok = col0_of(j) + l31 < nbase;
-      const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + tap * rkp + 8 * half;
+    // per tap: the rank-wide rows, then the D^T fragments of ALL column fragments in one batch, then the MFMAs (round 5: fragment
+    // by fragment every column fragment paid its own exposed round trip)
+    auto load_lb_batch = [&](int tap, int j0, bf16x8(&lbv)[JB][3]) {
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) lb[ks] = (cok && ks < nk) ? *(const bf16x8*)(lbp + 16 * ks) : zero8;
+      for (int jj = 0; jj < JB; ++jj) {
+        const int j = j0 + jj;
+        if (j >= FN || col0_of(j) >= nbase) continue;
+        const bool cok = col0_of(j) + l31 < nbase;
+        const bf16_t* lbp = LB + (unsigned)(n0 + (cok ? col0_of(j) + l31 : 0)) * (unsigned)p.lr_ldb + tap * rkp + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+          if (ks < nk) lbv[jj][ks] = *(const bf16x8*)(lbp + 16 * ks);
+      }
     };
     if (direct) {                                    // no mask, unit scale: the products go straight into the accumulators
       for (int tap = 0; tap < taps; ++tap) {
         load_la(tap);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          if (col0_of(j) >= nbase) continue;
-          bf16x8 lb[3];
-          load_lb(j, tap, lb);
+        for (int j0 = 0; j0 < FN; j0 += JB) {
+          bf16x8 lbv[JB][3];
+          load_lb_batch(tap, j0, lbv);
 #pragma unroll
-          for (int io = 0; io < NB; ++io) {
-            acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], acc[io][j], 0, 0, 0);
-            if (nk > 1) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], acc[io][j], 0, 0, 0);
-            if (nk > 2) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[2], la[io][2], acc[io][j], 0, 0, 0);
+          for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            if (j >= FN || col0_of(j) >= nbase) continue;
+#pragma unroll
+            for (int io = 0; io < NB; ++io) {
+              acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][0], la[io][0], acc[io][j], 0, 0, 0);
+              if (nk > 1) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][1], la[io][1], acc[io][j], 0, 0, 0);
+              if (nk > 2) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][2], la[io][2], acc[io][j], 0, 0, 0);
+            }
           }
         }
       }
-    } else {                                         // masked / scaled: one tap (launch_w8 checks), fragment by fragment
+    } else {                                         // masked / scaled: one tap (launch_w8 checks)
       load_la(0);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        if (col0_of(j) >= nbase) continue;
-        bf16x8 lb[3];
-        load_lb(j, 0, lb);
+      for (int j0 = 0; j0 < FN; j0 += JB) {
+        bf16x8 lbv[JB][3];
+        load_lb_batch(0, j0, lbv);
 #pragma unroll
-        for (int io = 0; io < NB; ++io) {
-          f32x16 tmp;
+        for (int jj = 0; jj < JB; ++jj) {
+          const int j = j0 + jj;
+          if (j >= FN || col0_of(j) >= nbase) continue;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
-          tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], tmp, 0, 0, 0);
-          if (nk > 1) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[1], la[io][1], tmp, 0, 0, 0);
-          if (nk > 2) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[2], la[io][2], tmp, 0, 0, 0);
-          finish(io, j, tmp);
+          for (int io = 0; io < NB; ++io) {
+            f32x16 tmp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+            tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][0], la[io][0], tmp, 0, 0, 0);
+            if (nk > 1) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][1], la[io][1], tmp, 0, 0, 0);
+            if (nk > 2) tmp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lbv[jj][2], la[io][2], tmp, 0, 0, 0);
+            finish(io, j, tmp);
+          }
         }
       }
     }
@@ -796,35 +843,14 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       const int ib0 = KG == 2 ? kg * OWN : 0;          // first band of the wave tile among this wave's own
       const bf16_t* Rp = (const bf16_t*)p.R;
       const bf16_t* rbp = (const bf16_t*)p.rowbias;
-      const float* biasp = (const float*)p.bias;
+      const float* sbias = (const float*)(smem + BIAS_OFF);            // the tile's bias, column-indexed from the tile origin
       const int half = lane >> 5;
-      // per-chunk operands, requested one fragment ahead of their use
-      struct Pre {
-        float4 b0, b1;
-        bf16x8 rb, rv;
-      };
       auto chunk_pos = [&](int io, int j, int qp, unsigned& row, int& ccol, bool& ok, bool& rk) {
         row = (unsigned)m0 + wr * TM + (ib0 + io) * 32 + (lane & 31);
         ccol = n0 + wc * TN + j * 32 + 8 * (qp + half);
         ok = row < (unsigned)M && (ccol - n0) < nbase;
         rk = p.n_split > 0 && ccol >= p.n_split;
       };
-      auto prefetch = [&](int ch, Pre& pf) {
-        unsigned row;
-        int ccol;
-        bool ok, rk;
-        chunk_pos((ch >> 1) / FN, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
-        if (ok && !rk) {
-          if (biasp) {
-            pf.b0 = *(const float4*)(biasp + ccol);
-            pf.b1 = *(const float4*)(biasp + ccol + 4);
-          }
-          if (rbp) pf.rb = *(const bf16x8*)(rbp + (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + ccol);
-          if (Rp) pf.rv = *(const bf16x8*)(Rp + row * (unsigned)p.ldr + ccol);
-        }
-      };
-      Pre cur, nxt;
-      if (KG == 2 && role == 0 && !LR) prefetch(0, cur);      // (in flight under the K-group exchange)
       if constexpr (KG == 2) {
         constexpr int PER = OWN * FN * 4 * 64;        // float4 slots per (receiving group, wave pair)
         float4* X = (float4*)smem;
@@ -916,11 +942,33 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           // (after the K-group exchange and the split-K reduction: the accumulators are complete — mode 2 multiplies them)
           if (p.lr_mode != 0) rank_phase(ib0, std::integral_constant<int, OWN>{});
         }
-        if (KG == 1 || role != 0 || LR) prefetch(0, cur);    // (the slab reduction / the rank phase need the registers)
+        // Round 5: three straight passes instead of one loop with guarded one-chunk-ahead prefetches.  (A) the row-bias / residual
+        // chunks of ALL chunks are requested at once (lanes outside the tile read the operand's first chunk: no divergent
+        // guard, nothing to wait for per chunk); (B) every chunk is finished into a packed bf16 register quad; (C) all stores
+        // go out back to back.  Before, loads and stores alternated and every chunk carried an `s_waitcnt vmcnt(0)`: on this
+        // target loads and stores share one counter but complete out of order with respect to each other, so waiting for a
+        // prefetched operand behind a store is a full drain — 6-12 exposed memory round trips per wave (the .s of the round-4
+        // build shows one vmcnt(0) per chunk; profiles/r03_w8_timeline.txt prices the epilogue at 11 000-18 000 cycles).
+        constexpr int NCH = 2 * OWN * FN;                // chunk = (fragment, quad pair)
+        // (one batched operand: the residual, else the row bias — a launch with BOTH fetches its row bias chunk by chunk)
+        const bf16_t* xp = Rp ? Rp : rbp;
+        bf16x8 xv[NCH];
+        if (xp) {
 #pragma unroll
-        for (int ch = 0; ch < 2 * OWN * FN; ++ch) {      // chunk = (fragment, quad pair)
+          for (int ch = 0; ch < NCH; ++ch) {
+            unsigned row;
+            int ccol;
+            bool ok, rk;
+            chunk_pos((ch >> 1) / FN, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
+            const unsigned off = !(ok && !rk) ? 0u : (Rp ? row * (unsigned)p.ldr + (unsigned)ccol
+                                                         : (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + (unsigned)ccol);
+            xv[ch] = *(const bf16x8*)(xp + off);
+          }
+        }
+        bf16x8 outv[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
           const int io = (ch >> 1) / FN, j = (ch >> 1) % FN, qp = 2 * (ch & 1);
-          if (ch + 1 < 2 * OWN * FN) prefetch(ch + 1, nxt);
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {                // (every lane takes part in the swap: before any row / column guard)
@@ -935,35 +983,46 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           int ccol;
           bool ok, rk;
           chunk_pos(io, j, qp, row, ccol, ok, rk);
-          if (ok) {
-            if (alpha != 1.f) {
+          if (alpha != 1.f) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= alpha;
+            for (int e = 0; e < 8; ++e) v[e] *= alpha;
+          }
+          if (!rk) {                                   // (rank columns: second output block, alpha only)
+            if (bias_lds) {
+              const int tc = wc * TN + j * 32 + 8 * (qp + half);      // (< BN: in range for every lane)
+              const float4 b0 = *(const float4*)(sbias + tc), b1 = *(const float4*)(sbias + tc + 4);
+              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+              v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
             }
-            if (rk) {                                  // rank columns: second output block, alpha only
-              *(bf16x8*)((bf16_t*)p.D2 + row * (unsigned)p.ldd2 + (ccol - p.n_split)) = pack8bf(v);
-            } else {
-              if (biasp) {
-                v[0] += cur.b0.x; v[1] += cur.b0.y; v[2] += cur.b0.z; v[3] += cur.b0.w;
-                v[4] += cur.b1.x; v[5] += cur.b1.y; v[6] += cur.b1.z; v[7] += cur.b1.w;
-              }
-              if (rbp) {
+            if (rbp) {
+              bf16x8 rb = xv[ch];
+              if (Rp) rb = *(const bf16x8*)(rbp + (ok ? (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + (unsigned)ccol : 0u));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bf2f((unsigned short)cur.rb[e]);
-              }
-              if (act_silu) {
+              for (int e = 0; e < 8; ++e) v[e] += bf2f((unsigned short)rb[e]);
+            }
+            if (act_silu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-              }
-              if (Rp) {
+              for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            }
+            if (Rp) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += beta * bf2f((unsigned short)cur.rv[e]);
-              }
-              *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + ccol) = pack8bf(v);
+              for (int e = 0; e < 8; ++e) v[e] += beta * bf2f((unsigned short)xv[ch][e]);
             }
           }
+          outv[ch] = pack8bf(v);
           if ((dbg & 8) && ch == 1) tl[6] = __builtin_readcyclecounter();
-          cur = nxt;
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          const int io = (ch >> 1) / FN, j = (ch >> 1) % FN, qp = 2 * (ch & 1);
+          unsigned row;
+          int ccol;
+          bool ok, rk;
+          chunk_pos(io, j, qp, row, ccol, ok, rk);
+          if (ok) {
+            if (rk) *(bf16x8*)((bf16_t*)p.D2 + row * (unsigned)p.ldd2 + (ccol - p.n_split)) = outv[ch];
+            else *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + ccol) = outv[ch];
+          }
         }
       }
     }
@@ -1164,7 +1223,7 @@ template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT
 int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BKT * 2;
   constexpr int EPI = EpiPlan<BN, WM, BM / WM / 32>::BYTES;
-  constexpr int SMEM = (RING > EPI ? RING : EPI) + 16;
+  constexpr int SMEM = (RING > EPI ? RING : EPI) + 16 + BN * 4;     // + split-K flag + the tile's bias (register epilogue)
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   T2V_CHECK_ARG(!(p.colsum && p.cs_mode == 2) || (!p.R && p.cs_x && p.cs_sums && p.cs_gamma && p.cs_beta && p.cs_G > 0 &&
                                                    p.cs_domain_rows % BM == 0 && p.cs_ldx % 8 == 0),
