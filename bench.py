@@ -419,29 +419,32 @@ def gemm_roofline(trainer, batch):
 
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel family in the step AS IT RUNS (every tile the shipped table selects),
-    from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r04_pmc_step.json: rocprofv3 --pmc
+    from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r05_pmc_step.json, else round 4's: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE, separate passes; PMC collection is slow and never part of the timed bench)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_step.json")) as f:
-            j = json.load(f)
-        fam = next(v for k, v in j["families"].items() if k.startswith("gemm_kernel_dma"))
-        return {"kernel_family": "gemm_kernel_dma<...> + gemm_w8_kernel<...> + gemm_skinny_kernel<MB>: all forward / backward-data launches of one C2 step",
-                "hbm_bytes_per_launch": fam["hbm_bytes_per_launch"], "hbm_GB_per_step": fam["hbm_GB_per_step"],
-                "launches_per_step": fam["launches_per_step"], "fetch_correction": j["fetch_correction"],
-                "source": "profiles/r04_pmc_step.json", "note": j.get("note")}
-    except Exception:   # noqa: BLE001
-        return None
+    for name in ("r05_pmc_step.json", "r04_pmc_step.json"):      # the newest committed counter passes
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                j = json.load(f)
+            fam = next(v for k, v in j["families"].items() if k.startswith("gemm_kernel_dma"))
+            return {"kernel_family": "gemm_kernel_dma<...> + gemm_w8_kernel<...> + gemm_skinny_kernel<MB>: all forward / backward-data launches of one C2 step",
+                    "hbm_bytes_per_launch": fam["hbm_bytes_per_launch"], "hbm_GB_per_step": fam["hbm_GB_per_step"],
+                    "launches_per_step": fam["launches_per_step"], "fetch_correction": j["fetch_correction"],
+                    "source": "profiles/" + name, "note": j.get("note")}
+        except Exception:   # noqa: BLE001
+            continue
+    return None
 
 
 def rocprof_family_time(algorithmic_flops):
     """The same family's kernel time in the steady-state GRAPH REPLAY of this bench, from the committed rocprofv3 kernel trace
-    (scripts/profile_bench.sh -> profiles/r04_bench_c2_kernel_stats.txt; pure kernel durations, no per-launch dispatch gap).
+    (scripts/profile_bench.sh -> profiles/r05_bench_c2_kernel_stats.txt; pure kernel durations, no per-launch dispatch gap).
     The live event pairs of the eager instrumented pass above also contain each launch's dispatch latency (~5 us x 955), which a
     graph replay overlaps with the previous kernel; both numbers are reported."""
     try:
         ms = 0.0
         n = 0
-        with open(os.path.join(ROOT, "profiles", "r04_bench_c2_kernel_stats.txt")) as f:
+        src = "r05_bench_c2_kernel_stats.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r05_bench_c2_kernel_stats.txt")) else "r04_bench_c2_kernel_stats.txt"
+        with open(os.path.join(ROOT, "profiles", src)) as f:
             for line in f:
                 if ("gemm_kernel_dma" in line or "gemm_w8_kernel" in line or "gemm_skinny_kernel" in line) and line.lstrip().startswith("_Z"):
                     parts = line.split()
@@ -451,7 +454,7 @@ def rocprof_family_time(algorithmic_flops):
             return None
         tf = algorithmic_flops / (ms * 1e-3) / 1e12
         return {"kernel_ms_per_step": round(ms, 2), "launches_per_step": n, "TFLOP/s": round(tf, 1),
-                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "source": "profiles/r04_bench_c2_kernel_stats.txt (config c2)"}
+                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "source": f"profiles/{src} (config c2)"}
     except Exception:   # noqa: BLE001
         return None
 

@@ -25,4 +25,3 @@ bash scripts/profile_bench.sh ${tag} > /dev/null 2>&1; head -8 gpurun_out/${tag}
 if [ "${3:-}" != "nopmc" ]; then
   bash scripts/pmc_step.sh ${tag}_pmc 2>&1 | tail -14
 fi
-fi
