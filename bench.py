@@ -549,7 +549,7 @@ def cpu_baseline(steps, device, c2_once=True):
                 eps_mse_rel_err=rel, eps_mse_cpu=l_cpu, eps_mse_gpu=l_gpu,
                 eps_mse_note="same seeded ModelScope-1.7B weights (lora_up ~ N(0, 0.02^2): live LoRA branches) and C1 batch: native "
                              "trainer loss on the GPU vs the CPU fp32 oracle, this run; full-size C1/C2 loss + every factor gradient "
-                             "against committed oracle fixtures: tests/test_lora_grads_gpu.py")
+                             "against committed oracle fixtures: tests/test_zz_fullsize_gpu.py")
 
 
 def _dist_info(world):
