@@ -92,7 +92,7 @@ def test_full_size_fixtures_carry_true_per_tensor_references():
     eval-mode fixtures the bf16-recipe floor of each of those tensors — otherwise the GPU test would silently fall back to the
     4-projection estimate whose chi^2_4 spread (0.4x .. 1.6x) tripped round 4's gate."""
     import torch
-    names = ["c1_s0", "c1_s0.02", "c1_s0.2", "c1_s0.02_drop", "c2_s0.02", "c2_s0.02_drop", "c3_s0", "c3full_s0"]
+    names = ["c1_s0", "c1_s0.02", "c1_s0.2", "c1_s1", "c1_s0.02_drop", "c2_s0.02", "c2_s0.02_drop", "c3_s0", "c3full_s0"]
     for nm in names:
         fx = torch.load(os.path.join(GOLDEN, f"oracle_step_{nm}.pt"), weights_only=False)
         assert "big" in fx and "big_sketch" in fx and fx["big_share"] == 1e-2, nm
