@@ -630,3 +630,16 @@ def test_merge_plan_refreshes_only_the_weights_that_are_read():
     assert all(e.merge_scale == 0.5 for e in ents) and g_mixed.merge_scale == 0.5
     plan._mark(())
     assert all(e.merge_scale is None for e in ents) and g_off.merge_scale is None
+
+
+def test_full_size_fixture_tests_collect_last():
+    """a gate tripping in the minutes-long full-size fixture tests must not hide the train / UNet / VAE / CLIP tests from a
+    `pytest -x` run — they live in the file that sorts last, and no other GPU test file loads a full-size fixture."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(f for f in os.listdir(here) if f.startswith("test_") and f.endswith(".py"))
+    assert files[-1] == "test_zz_fullsize_gpu.py"
+    needles = ("_load_" + "fixture(", "fixture_" + "path(")          # (split: this file must not match itself)
+    for f in files[:-1]:
+        src = open(os.path.join(here, f)).read()
+        assert not any(n in src for n in needles), f
