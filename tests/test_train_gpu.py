@@ -175,8 +175,12 @@ def test_pipelined_replays_without_host_sync_follow_the_eager_trajectory(host_ba
     from t2v_amd.training import DenoiseTrainer
     _, _, dunet, dvae, _ = _build(r=4)
     dunet2 = copy.deepcopy(dunet)
-    t1 = DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=1e-4)
-    t2 = DenoiseTrainer(dunet2, dvae, [p for p in dunet2.parameters() if p.requires_grad], lr=1e-4)
+    # (lr 1e-5: AdamW's first steps are sign-like, so the fp32-atomic noise of one step's gradients flips update signs and the
+    #  trajectories of two EAGER runs drift apart by ~lr per step — at 1e-4 they differed by up to 2.4e-3 after five updates
+    #  (profiles/r05_pytest_*.log), as much as the bar should catch; at 1e-5 the noise is ~10x smaller while a wrong INPUT —
+    #  the hazards this test exists for — moves the loss as before)
+    t1 = DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=1e-5)
+    t2 = DenoiseTrainer(dunet2, dvae, [p for p in dunet2.parameters() if p.requires_grad], lr=1e-5)
     cpu = [synthetic_batch(4, 64, 64, seed=100 + i, text_dim=64) for i in range(6)]
     dev = [{k: v.cuda() for k, v in b.items()} for b in cpu]
     if host_batches:
@@ -190,11 +194,12 @@ def test_pipelined_replays_without_host_sync_follow_the_eager_trajectory(host_ba
     for i, (a, b) in enumerate(zip(got, want)):
         rel = abs(a.item() - b.item()) / abs(b.item())
         print(f"step {i}: replay {a.item():.6f} eager {b.item():.6f} rel {rel:.2e}")
-        # step 0 is exact; later steps sit 3e-4 .. 9e-4 off (AdamW's sign-like first updates amplify 1-ulp differences).  Round 4
-        # saw step 3 of the host-batch run 2.8e-3 .. 3.7e-3 off while the two prepare graphs shared one capture pool (slot 1's batch
-        # sat on the other graph's intermediates); each prepare graph records into its own pool since.  ONE bar for both forms: a
-        # tolerance is not sized to a known-wrong result.
-        assert rel < (1e-5 if i == 0 else 5e-3)
+        # step 0 is exact; later steps sit 0 .. 6e-4 off at this learning rate (AdamW's sign-like first updates amplify the 1-ulp
+        # differences of the fp32-atomic gradient sums; 18 trajectories measured in round 5: 0, 2.5e-4, 4.0e-4, 5.9e-4).  Round 4 saw
+        # step 3 of the host-batch run 2.8e-3 .. 3.7e-3 off while the two prepare graphs shared one capture pool (slot 1's batch sat
+        # on the other graph's intermediates); each prepare graph records into its own pool since, and both forms now replay the
+        # same losses.  ONE bar for both forms, below the size of that hazard: a tolerance is not sized to a known-wrong result.
+        assert rel < (1e-5 if i == 0 else 2e-3)
     assert len({round(v.item(), 5) for v in want}) == 6          # the batches really differ
     assert relerr(t2.opt.flat_p, t1.opt.flat_p) < 1e-2
 
