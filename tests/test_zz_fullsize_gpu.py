@@ -54,9 +54,10 @@ def _fixture_tools():
 #   floor arm (dropout / C2 / C3 fixtures: one oracle run only).  Every committed fixture carries these references
 #   (tests/test_parity_floor.py::test_full_size_fixtures_carry_true_per_tensor_references); the 4-projection estimate of rounds
 #   3-4 is still printed beside them.
-# Measured (profiles/r05_parity.jsonl, first full run of round 5): amplitudes 0 / 0.02, eval and default mode: worst true error
-# 0.126 - 0.138, every tensor BELOW its own bf16-recipe floor (0.13 - 0.17); amplitude 0.2: 0.273 on the to_q tensor above (floor
-# 0.294), worst ratio to the floor 1.36 (down_blocks.2.attentions.0 ... to_v: 0.235 vs 0.173).
+# Measured (profiles/r05_parity.jsonl, identical in the three full runs of round 5): C1 amplitudes 0 / 0.02: worst true error 0.138 /
+# 0.137, every tensor BELOW its own bf16-recipe floor (0.13 - 0.17); amplitude 0.2: 0.273 on the to_q tensor above (floor 0.294), worst
+# ratio to the floor 1.36 (down_blocks.2.attentions.0 ... to_v: 0.235 vs 0.173); fixtures without a floor arm: C1 default mode 0.127,
+# C2 0.146, C2 default mode 0.128, C3 0.153 / 0.152.
 MIN_TENSOR_FLOOR = 0.10
 TRUE_TENSOR_BAR = 0.25
 
