@@ -221,8 +221,9 @@ def sampled_names(names, every=12):
 
 
 # ---------------------------------------------------------------------------------------------- shared by the model-level parity tests
-FLOOR_FACTOR = 2.0          # a native result is accepted within 2x the error of the reference's own bf16 recipe (autocast floor)
-RESULTS = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "parity_r05.jsonl")
+FLOOR_FACTOR = 1.6          # a native result is accepted within 1.6x the error of the reference's own bf16 recipe (autocast floor);
+                            # round 6: 2.0 -> 1.6 (worst ratio measured over rounds 3-5: 1.36 per tensor, 1.29 whole gradient)
+RESULTS = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "parity_r06.jsonl")
 
 
 def floor_row(config, scale):

@@ -59,7 +59,7 @@ def _fixture_tools():
 # ratio to the floor 1.36 (down_blocks.2.attentions.0 ... to_v: 0.235 vs 0.173); fixtures without a floor arm: C1 default mode 0.127,
 # C2 0.146, C2 default mode 0.128, C3 0.153 / 0.152.
 MIN_TENSOR_FLOOR = 0.10
-TRUE_TENSOR_BAR = 0.25
+TRUE_TENSOR_BAR = 0.20      # round 6: 0.25 -> 0.20 (measured 0.127 - 0.153 on the five fixtures without a floor arm)
 
 
 def _compare_with_fixture(fx, gd):

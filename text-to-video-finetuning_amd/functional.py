@@ -302,6 +302,32 @@ def check_gemm_workspaces():
                            "step are wrong; the arrival counters have been re-armed")
 
 
+def gemm_workspace_flags_async():
+    """Enqueue a copy of every GEMM workspace's give-up word into pinned host memory (each on the current stream, behind the work
+    already queued there) and return (event, [(key, workspace, pinned word)]) for `raise_on_gemm_flags` — the non-stalling form of
+    `check_gemm_workspaces` that `DenoiseTrainer` polls every few steps."""
+    items = []
+    for key, buf in list(_gemm_ws.items()):
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(buf[16383:16384].view(torch.int32), non_blocking=True)
+        items.append((key, buf, host))
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev, items
+
+
+def raise_on_gemm_flags(pending):
+    ev, items = pending
+    ev.synchronize()
+    bad = [key for key, _, host in items if int(host[0]) == 0xdead]
+    if bad:
+        for key, buf, _ in items:
+            if key in bad:
+                buf[:16384].zero_()
+        raise RuntimeError(f"t2v_gemm: an in-launch split-K reduction timed out on (device, stream) {bad}: the gradients of a recent "
+                           "step are wrong (restore the last checkpoint); the arrival counters have been re-armed")
+
+
 def _split_k(tiles, kdim):
     """K splits of a K-major launch with `tiles` 64x64 output tiles: about 1600 workgroups (measured optimum of the weight-
     gradient signatures at 320^2 .. 1280^2 outputs, scripts/kmajor_probe.py), at least 128 reduction rows per split."""

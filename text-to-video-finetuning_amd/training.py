@@ -210,7 +210,8 @@ class FlatAdamW:
         return {"steps_done": int(self.steps_done), "numel": int(self.numel), "layout": self._layout_fingerprint(),
                 "exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
                 "step_count": self.step_count.detach().clone(),
-                "dropout": {"base": int(leaves._seed_state["base"]), "step": int(leaves._seed_state["step"])}}
+                "dropout": {"base": int(leaves._seed_state["base"]), "step": int(leaves._seed_state["step"]),
+                            "fwd": int(leaves._seed_state["fwd"])}}
 
     def load_state_dict(self, sd):
         if int(sd["numel"]) != int(self.numel):
@@ -225,7 +226,8 @@ class FlatAdamW:
         if "dropout" in sd:
             from .models import leaves
             leaves._seed_state["base"], leaves._seed_state["step"] = int(sd["dropout"]["base"]), int(sd["dropout"]["step"])
-            leaves._seed_state["fwd"] = -1
+            # (index of the root forward inside an accumulation window: a mid-window resume must not redraw micro-step 0's masks)
+            leaves._seed_state["fwd"] = int(sd["dropout"].get("fwd", -1))
 
     def zero_grad(self, set_to_none=False):
         from .functional import clear_bwd_colsums, drop_pending_wgrads
@@ -301,6 +303,10 @@ class DenoiseTrainer:
             self.opt.lr_schedule = lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps, base_lr=lr)
         self.gas = max(1, int(gradient_accumulation_steps))      # train.py:481,519,848 (`accelerator.accumulate`)
         self._micro = 0
+        self._window_loss = None
+        self._flag_every = max(0, int(os.environ.get("T2V_FLAG_CHECK_EVERY", "64")))     # steps between device-flag reads (0: never)
+        self._flag_steps = 0
+        self._flag_pending = None                  # (event, pinned words) of the read enqueued at the previous check point
         self.pg, self.world = process_group, world_size
         self.rank = 0
         if world_size > 1:
@@ -468,7 +474,25 @@ class DenoiseTrainer:
         self._micro = 0
         mean = self._window_loss / self.gas if self.gas > 1 else loss
         self._window_loss = None
-        return self._exchange_and_update(mean)
+        out = self._exchange_and_update(mean)
+        self._poll_device_flags()
+        return out
+
+    def _poll_device_flags(self):
+        """Split-K give-up word (gemm_w8.hip: a reducer that timed out stores 0xdead and sums incomplete slabs) WITHOUT stalling
+        the step pipeline: every `T2V_FLAG_CHECK_EVERY` optimiser steps the flag words of all GEMM workspaces are copied to pinned
+        host memory behind the step just issued, and the copy enqueued at the PREVIOUS check point — long complete — is read.  A
+        time-out therefore raises at most two intervals after the step it spoiled instead of staying silent until the next
+        checkpoint (`state_dict` still reads the flags synchronously)."""
+        if not self._flag_every:
+            return
+        self._flag_steps += 1
+        if self._flag_steps % self._flag_every:
+            return
+        from .functional import gemm_workspace_flags_async, raise_on_gemm_flags
+        prev, self._flag_pending = self._flag_pending, gemm_workspace_flags_async()
+        if prev is not None:
+            raise_on_gemm_flags(prev)
 
     def train_step(self, batch):
         return self._micro_step(lambda: self._fwd_bwd(batch))
@@ -484,16 +508,36 @@ class DenoiseTrainer:
         LoRA files, train.py:911-935): the optimiser state (moments, step counter, LR-schedule position, dropout step) and the
         device-side dropout epoch of this trainer's captured / eager steps."""
         self.check_device_flags()          # a checkpoint is a natural sync point: no split-K hand-off gave up since the last one
-        ep = None if self._drop_epoch is None else int(self._drop_epoch.item())
-        return {"opt": self.opt.state_dict(), "drop_epoch": ep, "micro": int(self._micro)}
+        # the epoch is stored WITHOUT this rank's 2^32 offset: every rank of a resumed run loads the usual rank-0 file and must
+        # keep drawing its own masks (ADVICE r5)
+        ep = None if self._drop_epoch is None else int(self._drop_epoch.item()) - (int(self.rank) << 32)
+        sd = {"opt": self.opt.state_dict(), "drop_epoch": ep, "drop_epoch_rank_free": True, "micro": int(self._micro)}
+        if self._micro > 0:
+            # mid-window checkpoint (gradient accumulation): the partial gradient sum and the running window loss belong to the
+            # state — without them a resumed run would apply a partial gradient scaled by 1/window (ADVICE r5)
+            sd["window_grad"] = self.opt.flat_g_full.detach().clone()
+            sd["window_loss"] = None if self._window_loss is None else self._window_loss.detach().clone()
+        return sd
 
     def load_state_dict(self, sd):
         self.opt.load_state_dict(sd["opt"])
         if sd.get("drop_epoch") is not None:
             if self._drop_epoch is None:
                 self._drop_epoch = torch.zeros(1, dtype=torch.int64, device=self.opt.flat_p.device)
-            self._drop_epoch.fill_(int(sd["drop_epoch"]))       # in place: a captured step reads this address
+            ep = int(sd["drop_epoch"])
+            if sd.get("drop_epoch_rank_free"):
+                ep += int(self.rank) << 32                      # this rank's own mask stream
+            self._drop_epoch.fill_(ep)                          # in place: a captured step reads this address
         self._micro = int(sd.get("micro", 0))
+        self._window_loss = None
+        if self._micro > 0:
+            if sd.get("window_grad") is None:                   # (a file of an older build: the window cannot be continued)
+                self._micro = 0
+            else:
+                self.opt._ensure_homed()
+                self.opt.flat_g_full.copy_(sd["window_grad"])
+                wl = sd.get("window_loss")
+                self._window_loss = None if wl is None else wl.to(self.opt.flat_p.device).clone()
         self.opt.refresh_bf16()
 
     # ---- HIP-graph replay of forward+backward (static shapes)
