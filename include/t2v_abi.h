@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 7   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
+#define T2V_ABI_VERSION 8   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -135,7 +135,16 @@ typedef struct {
    *              the down factor in the layout of B) as extra weight rows behind its base columns; their accumulators t are
    *              rounded to bf16, written to D2 [M, ldd2] (the saved down-projection of the backward) and multiplied with LB in
    *              the epilogue: y = x W^T + s mask (t U^T) in one launch, with no pass over y.  N counts the base columns only;
-   *              n_split must be 0, lr_taps 1. */
+   *              n_split must be 0, lr_taps 1.
+   *   lr_mode 3 (ABI v8): the backward-data launch of a dropped LINEAR wrapper (or projection group) that forms its own dt:
+   *              A = dy (dense), B = W^T layout, N = C_in; B2 = the up factor(s) rank-major, bf16 [lr_rp, ldb2] over K (members of a
+   *              group side by side / block diagonal with the zeros stored), lr_rp <= 64 total ranks.  The launch computes
+   *                dt[m, j] = 1/(1-p) sum_k keep(seed_i, m * W + (k - i W)) dy[m, k] B2[j, k]        (i = k / W, the member of column k)
+   *              with W = lr_group_cols (the members' K width; 0: one member, W = K) — the mask each member drew in its forward
+   *              launch (lr_drop_seed, lr_group_seed[0..1]) is applied to the A fragments of the rank columns' MFMAs, hashed in
+   *              the K loop — writes dt (bf16) to D2 [M, ldd2] and adds dt LB^T (LB = lr_b [N, lr_ldb] = (s D)^T, the scale folded
+   *              in: lr_scale must be 1) to D in its epilogue: dx = dy W + s dt D with NO separate t2v_lora_drop_dt launch.
+   *              n_split must be 0, lr_taps 1, M * W < 2^34. */
   int lr_mode; int lr_rp; int lr_taps;
   const void* lr_a; long long lr_lda;
   const void* lr_b; long long lr_ldb;
@@ -151,6 +160,14 @@ typedef struct {
    * models/unet_3d_blocks.py:312: t2v_gn_apply's drop_p): the incoming gradient is masked first, dz = keep(cs_drop_seed,
    * m * Nb + n) ? y / (1 - cs_drop_p) : 0 — what t2v_gn_bwd_stats does with its drop_p / drop_seed.  0: no dropout. */
   float cs_drop_p; unsigned long long cs_drop_seed;
+  /* ABI v8 — keep-bit plane of the dropped LoRA branch (optional, may be NULL): the forward launch (lr_mode 2), which hashes the
+   * mask of its output anyway, WRITES the keep bits; the backward-data launch of the same layer (lr_mode 3) READS them instead of
+   * hashing the mask again inside its K loop.  For a mask matrix [M, W] (W % 32 == 0) the plane holds M * W / 8 bytes, fragment-
+   * major: 16-bit word (j, row, h) at byte ((j * M + row) * 2 + h) * 2, j = column >> 5, h = 0 / 1; bit b of it = keep of column
+   * 32 j + 8 (b >> 2) + 4 h + (b & 3) — the register order of the 8-wave kernels' transposed accumulators, so that a wave's 64
+   * words of a fragment are one 128-byte line.  Projection groups: member i's plane (W = lr_group_cols) starts at byte
+   * i * M * W / 8.  The plane is per FORWARD (the dropout epoch is already folded in): no seed is needed to read it. */
+  void* lr_plane;
 } T2VGemm;
 /* Kernel selection is the library's: the shipped tile table / heuristic picks a 4-wave or an 8-wave tiled kernel; a plain dense
  * NN descriptor with M <= 96 and K % 64 == 0 (no rank columns, statistics, rank-wide term or batch; bf16 output) runs on the
@@ -161,7 +178,8 @@ int t2v_gemm(const T2VGemm* p, t2v_stream_t stream);
  * shipped tile table / heuristic; 0 during live tuning runs). */
 int t2v_gemm_colsum_rows(const T2VGemm* p);
 /* 1 if t2v_gemm runs this descriptor WITH its rank-wide epilogue term (lr_mode != 0: the 8-wave kernels' domain — K%64, window
- * C%64, bf16 output, 32-bit offsets), else 0: the caller then evaluates the LoRA branch with separate launches. */
+ * C%64, bf16 output, 32-bit offsets; mode 3 additionally: dense A, <= 64 ranks, members of whole 64-column stages), else 0: the
+ * caller then evaluates the LoRA branch with separate launches. */
 int t2v_gemm_lr_ok(const T2VGemm* p);
 /* Pinned launch on one of the 8-wave, one-workgroup-per-CU configurations of csrc/gemm_w8.hip (what t2v_gemm selects through
  * the tile table for lean descriptors: K%64==0, window C%64==0, bf16 output, no dropout / batch); for tuning runs, the

@@ -891,6 +891,19 @@ def test_attention_deferred_rescale_branch():
 
 # ----------------------------------------------------------------------------------------------------------------------
 # 8-wave GEMM configurations (csrc/gemm_w8.hip) through the C ABI: every configuration, column steps, in-launch split-K
+def _keep_plane(keep):
+    """The keep-bit plane of T2VGemm.lr_plane for a bool mask [M, W] (W % 32 == 0), restated from include/t2v_abi.h: 16-bit word
+    (j, row, h) at halfword (j * M + row) * 2 + h; bit b = keep of column 32 j + 8 (b >> 2) + 4 h + (b & 3)."""
+    import numpy as np
+    M, W = keep.shape
+    k = keep.numpy().astype(np.uint32).reshape(M, W // 32, 4, 2, 4)          # [row, j, b >> 2, h, b & 3]
+    words = np.zeros((W // 32, M, 2), dtype=np.uint32)
+    for q in range(4):
+        for e in range(4):
+            words |= k[:, :, q, :, e].transpose(1, 0, 2) << (4 * q + e)
+    return torch.from_numpy(words.astype(np.uint16).view(np.int16).reshape(-1).copy())
+
+
 def _w8_problem(M, N, rc, K, taps, res, seed=0):
     import t2v_amd.functional as F
     import t2v_amd.native as nv
@@ -1009,16 +1022,26 @@ def test_w8_rank_epilogue_term_forward(M, N, K, taps, rp, res, p_drop):
     ref = base + (r.float().cpu() if res else 0) + s * m * (tref.float() @ UT.float().cpu()[:, :rp].T)
     assert relerr(t, tref) < 1e-2          # (the unfused launch's t: same rounding point)
     scale = float(ref.abs().max())
+    # (round 6) the launch also leaves the keep bits of its mask for the backward-data launch (T2VGemm.lr_plane)
+    plane = pref = None
+    if p_drop > 0 and N % 32 == 0:
+        plane = torch.zeros(M * N // 16, dtype=torch.int16, device="cuda")
+        pref = _keep_plane(keep_mask(seed, M, N, p_drop))
+        kw["lr"]["plane"] = plane.data_ptr()
     desc = F.make_gemm(**kw)
     assert nv.lib().t2v_gemm_lr_ok(C.byref(desc)) == 1
     for cfg in (12, 17, 21, 22, 14, 16, 19, 20):      # (14, 16, 19, 20: K-group configurations, rank phase after the groups met)
         for nstep, splits in ((0, 1), (160, 1), (0, 2), (96, 3)):
             d.zero_(); t.zero_()
+            if plane is not None:
+                plane.zero_()
             nv.call("t2v_gemm_w8", C.byref(desc), cfg, nstep, splits, nv.stream())
             torch.cuda.synchronize()
             err = float((d.float().cpu() - ref).abs().max()) / scale
             et = relerr(t, tref)
             assert err < 1.2e-2 and et < 1e-2, (cfg, nstep, splits, err, et)
+            if plane is not None:
+                assert torch.equal(plane.cpu(), pref), (cfg, nstep, splits, "keep-bit plane")
     # through t2v_gemm (heuristic configuration), with the GroupNorm column statistics of the FINAL output
     if N % 32 == 0 and M % 128 == 0:
         d.zero_()
@@ -1099,6 +1122,89 @@ def test_w8_rank_epilogue_term_from_memory(M, N, K, taps, rp, res, masked):
     nv.call("t2v_gemm", C.byref(desc), nv.stream())
     torch.cuda.synchronize()
     assert float((d.float().cpu() - ref).abs().max()) / scale < 1.2e-2
+
+
+@pytest.mark.parametrize("M,N,K,members,rpe,res,p_drop", [(512, 320, 320, 1, 16, 0, 0.1), (1152, 640, 1920, 3, 16, 0, 0.1),
+                                                            (300, 1280, 1280, 1, 32, 1, 0.25), (640, 320, 2560, 1, 8, 0, 0.1),
+                                                            (512, 640, 1280, 2, 32, 0, 0.1), (256, 1280, 320, 1, 24, 1, 0.0),
+                                                            (384, 320, 640, 2, 16, 0, 0.1)])
+def test_w8_rank_epilogue_term_dt_in_launch(M, N, K, members, rpe, res, p_drop):
+    """T2VGemm.lr_mode 3 (round 6) — the backward-data launch of a dropped linear wrapper / projection group forms dt itself:
+    dt = bf16(1/(1-p) (mask dy) U^T) from rank fragments whose MFMAs take masked A fragments (member i of a group = K block i with
+    its own seed and mask width), written to D2, and D = dy W^T + bias + R + dt LB^T.  Against torch fp32 on the bf16 operands with
+    the protocol masks (oracle/dropout.py), over the LR configurations x column steps x K splits, and through t2v_gemm with the
+    column statistics of the stored output (staged epilogue)."""
+    import ctypes as C
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    from oracle.dropout import keep_mask
+    kw, d, _, keep = _w8_problem(M, N, 0, K, 1, res, seed=M + K + rpe + members)
+    a, w, b, r = keep[0], keep[1], keep[2], keep[3]
+    g = torch.Generator().manual_seed(123 + rpe + members)
+    rp, W = rpe * members, K // members
+    rk = 16 * ((rp + 15) // 16)
+    U = torch.zeros(rp, K)
+    for i in range(members):                        # block diagonal, zeros stored (lora_bank's group layout)
+        U[i * rpe:(i + 1) * rpe, i * W:(i + 1) * W] = torch.randn(rpe, W, generator=g) * W ** -0.5
+    U = _bf(U).cuda()
+    LB = torch.zeros(N, rk); LB[:, :rp] = torch.randn(N, rp, generator=g) * 0.3
+    LB = _bf(LB).cuda()
+    dt = torch.zeros(M, rp, dtype=torch.bfloat16, device="cuda")
+    seeds = [0xABCD01, 0x1234567, 0x7654321][:members]
+    kw.update(B2=U.data_ptr(), ldb2=K, D2=dt.data_ptr(), ldd2=rp,
+              lr=dict(mode=3, rp=rp, b=LB.data_ptr(), ldb=rk, drop_p=p_drop, drop_seed=seeds[0],
+                      group_cols=W if members > 1 else 0, group_seeds=seeds[1:]))
+    af = a.float().cpu()
+    if p_drop > 0:
+        m = torch.cat([keep_mask(seeds[i], M, W, p_drop).float() for i in range(members)], 1) / (1.0 - p_drop)
+    else:
+        m = torch.ones(M, K)
+    dtref = _bf((m * af) @ U.float().cpu().T)
+    ref = af @ w.float().cpu().T + b.cpu() + (r.float().cpu() if res else 0) + dtref.float() @ LB.float().cpu()[:, :rp].T
+    scale = float(ref.abs().max())
+    desc = F.make_gemm(**kw)
+    assert nv.lib().t2v_gemm_lr_ok(C.byref(desc)) == 1
+    descs = [("hash", desc)]
+    if p_drop > 0 and W % 64 == 0:
+        # the same launch reading the keep bits from the plane the forward launch left (member i at byte i * M * W / 8); WRONG seeds
+        # prove that the bits, not a hash, decide
+        plane = torch.cat([_keep_plane(keep_mask(seeds[i], M, W, p_drop)) for i in range(members)]).cuda()
+        kwp = dict(kw)
+        kwp["lr"] = dict(kw["lr"], plane=plane.data_ptr(), drop_seed=1, group_seeds=[2, 3][:members - 1])
+        descs.append(("plane", F.make_gemm(**kwp)))
+    for how, dsc in descs:
+        for cfg in (12, 17, 21, 22, 14, 16, 19, 20):
+            for nstep, splits in ((0, 1), (160, 1), (0, 2), (96, 3)):
+                d.zero_(); dt.zero_()
+                nv.call("t2v_gemm_w8", C.byref(dsc), cfg, nstep, splits, nv.stream())
+                torch.cuda.synchronize()
+                err = float((d.float().cpu() - ref).abs().max()) / scale
+                et = relerr(dt, dtref)
+                assert err < 1.2e-2 and et < 1e-2, (how, cfg, nstep, splits, err, et)
+    d.zero_(); dt.zero_()
+    nv.call("t2v_gemm", C.byref(desc), nv.stream())        # whatever t2v_gemm selects on its own
+    torch.cuda.synchronize()
+    assert float((d.float().cpu() - ref).abs().max()) / scale < 1.2e-2 and relerr(dt, dtref) < 1e-2
+    if N % 32 == 0 and M % 128 == 0:                        # staged epilogue: column statistics of the FINAL output ride along
+        d.zero_(); dt.zero_()
+        import os
+        os.environ["T2V_GEMM_FORCE_CFG"] = "117,10,1"
+        try:
+            info = F.launch_gemm(cs={"mode": 1}, **kw)
+        finally:
+            del os.environ["T2V_GEMM_FORCE_CFG"]
+        assert info is not None
+        buf, bm, mm, nb = info
+        G, nd = 32, 1
+        sums = torch.empty(nd * G * 2, device="cuda"); refs = torch.empty_like(sums)
+        nv.call("t2v_gn_finish", buf.data_ptr(), nd, M, N, G, sums.data_ptr(), nv.stream())
+        ws = F._gn_workspace(nd, G, d.device)
+        nv.call("t2v_gn_stats", d.data_ptr(), N, nd, M, N, G, refs.data_ptr(), ws.data_ptr(), nv.stream())
+        torch.cuda.synchronize()
+        assert float((d.float().cpu() - ref).abs().max()) / scale < 1.2e-2 and relerr(dt, dtref) < 1e-2
+        assert relerr(sums, refs) < 1e-5
+    ws = F._gemm_workspace()
+    assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "split-K counters must be left zero"
 
 
 @pytest.mark.parametrize("force", ["114,0,1", "113,0,1", "2,2,1", "0,0,1", "112,5,2"])

@@ -9,6 +9,10 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libt2v_hip.so")
 SOURCES = ["gemm.hip", "gemm_w8.hip", "norm.hip", "attn.hip", "elementwise.hip", "lora_wgrad.hip", "lora_merge.hip"]
+# translation units: (source, object, extra flags).  gemm_w8.hip is compiled three times with -DW8_PART=0/1/2 (plain kernels + entry
+# points / LR = 1 kernels / LR = 2 kernels): its ~60 kernel instantiations took 3 minutes in one hipcc process
+UNITS = [(s, s.replace(".hip", ".o"), []) for s in SOURCES if s != "gemm_w8.hip"] + \
+        [("gemm_w8.hip", f"gemm_w8_p{i}.o", [f"-DW8_PART={i}"]) for i in range(3)]
 
 
 def _digest():
@@ -42,10 +46,11 @@ def build(force=False, verbose=True):
     with open(os.path.join(INCLUDE, "t2v_abi.h"), "rb") as fh:
         hh.update(fh.read())
     stamps = {}
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+    for src, oname, flags in UNITS:
+        obj = os.path.join(CSRC, oname)
         objs.append(obj)
         h = hh.copy()
+        h.update(" ".join(flags).encode())
         with open(os.path.join(CSRC, src), "rb") as fh:
             h.update(fh.read())
         stamps[obj] = h.hexdigest()
@@ -53,12 +58,12 @@ def build(force=False, verbose=True):
         if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == stamps[obj]:
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
-               "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Wno-unused-result"] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for src, pr in procs:
+    for src, obj, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             failed = True
@@ -66,7 +71,6 @@ def build(force=False, verbose=True):
         else:
             if verbose and out.strip():          # warnings: shown, and the object is stamped all the same (it did compile)
                 print(out)
-            obj = os.path.join(CSRC, src.replace(".hip", ".o"))
             with open(obj + ".sha256", "w") as f:
                 f.write(stamps[obj])
     if failed:

@@ -1056,7 +1056,7 @@ int colsum_bm(const T2VGemm& p, const DmaCfg& c) {
   if (c.tile >= W8_BASE) {
     const int w = c.tile - W8_BASE;
     // (mode 2 multiplies COMPLETE accumulators: the staged epilogue of a K-group configuration sums the groups too late)
-    if (p.lr_mode == 2 && (w == 14 || w == 16 || w == 19 || w == 20 || c.split > 1)) return 0;
+    if ((p.lr_mode == 2 || p.lr_mode == 3) && (w == 14 || w == 16 || w == 19 || w == 20 || c.split > 1)) return 0;
     return t2v_gemm_w8_bm(w);
   }
   static const int no_epi = [] { const char* e = getenv("T2V_GEMM_EPI"); return e && e[0] == '0'; }();
@@ -1205,11 +1205,16 @@ int lr_w8_bn(int w) { return (w == 14 || w == 19) ? 192 : ((w == 16 || w == 20) 
 
 DmaCfg lr_heuristic_cfg(const T2VGemm& p) {
   const bool lr2 = p.lr_mode == 2;
+  const int rkc = p.lr_mode == 3 ? 32 * ((p.lr_rp + 31) / 32) : (lr2 ? 32 : 0);     // tile columns taken by the rank fragments
   // first choice: what the table holds for the SAME GEMM without the term — the rank-column launch [y | t] (forward) or the plain
   // launch (backward-data) — when that is an 8-wave configuration with an LR instantiation
-  {
+  for (int pass = p.lr_mode == 3 ? 0 : 1; pass < 2; ++pass) {
     T2VGemm q = p;
     q.lr_mode = 0;
+    if (pass == 0) {                               // mode 3: first what the table holds for the mode-1 form of the same launch
+      q.lr_mode = 1;
+      q.lr_group_cols = 0;
+    }
     if (lr2) {
       q.N = p.N + p.lr_rp * (p.lr_group_cols > 0 ? p.N / p.lr_group_cols : 1);
       q.n_split = p.N;
@@ -1221,9 +1226,22 @@ DmaCfg lr_heuristic_cfg(const T2VGemm& p) {
       DmaCfg c = it->second;
       const int w = c.tile - W8_BASE, bn = lr_w8_bn(w);
       int step = c.stages > 0 ? c.stages * 32 : bn;
-      if (lr2 && step > bn - 32) step = bn - 32;
-      c.stages = step / 32;
-      return c;
+      if (p.lr_mode == 3 && step > bn - rkc) {
+        // the rank fragments of mode 3 do not fit behind the borrowed column step: keep the step (and with it the number of
+        // column tiles) and take the next wider tile of the same family instead of cutting the step
+        int w2 = w == 14 ? 16 : (w == 19 ? 20 : (w == 16 ? 12 : (w == 20 ? 17 : -1)));
+        while (w2 >= 0 && step > lr_w8_bn(w2) - rkc) w2 = w2 == 16 ? 12 : (w2 == 20 ? 17 : -1);
+        if (w2 >= 0) {
+          c.tile = W8_BASE + w2;
+          c.stages = step / 32;
+          return c;
+        }
+      }
+      if (step > bn - rkc) step = bn - rkc;
+      if (step >= 32) {
+        c.stages = step / 32;
+        return c;
+      }
     }
   }
   struct Cand { int cfg, bm, bn, kg; };
@@ -1232,7 +1250,8 @@ DmaCfg lr_heuristic_cfg(const T2VGemm& p) {
   double best = 1e300;
   DmaCfg out{W8_BASE + 17, 0, 1};
   for (const Cand& c : cands) {
-    const int bn_eff = lr2 ? c.bn - 32 : c.bn;
+    const int bn_eff = c.bn - rkc;
+    if (bn_eff < 32) continue;
     int ntn = (p.N + bn_eff - 1) / bn_eff;
     int step = ((p.N + ntn - 1) / ntn + 31) / 32 * 32;           // even split of N into whole fragments
     if (step > bn_eff) step = bn_eff;
@@ -1243,7 +1262,7 @@ DmaCfg lr_heuristic_cfg(const T2VGemm& p) {
                      65536ll + tiles * sp * c.bm * c.bn * 4 > (long long)p.workspace_bytes || tiles > 8000))
         continue;
       const long long rounds = (tiles * sp + 255) / 256;
-      const double cols = step + (lr2 ? 32 : 0);
+      const double cols = step + rkc;
       const double cost = (double)rounds * c.bm * cols * ((double)p.K / sp + 1536.0 + (sp > 1 ? 768.0 : 0.0));
       if (cost < best) {
         best = cost;
@@ -1296,9 +1315,11 @@ DmaCfg pick_cfg(const T2VGemm& p, hipStream_t s) {
     // launches with a rank-wide epilogue term: the LR instantiations of the 8-wave family x column steps x K splits
     static const int W8LR[][3] = {{12, 128, 384}, {17, 128, 384}, {21, 128, 384}, {22, 128, 384}, {14, 128, 192}, {19, 128, 192},
                                   {16, 128, 256}, {20, 128, 256}};
-    const bool lr2 = p.lr_mode == 2;
+    const bool lr2 = p.lr_mode == 2 || p.lr_mode == 3;      // (column tiles of nstep base columns + rank fragments)
+    const int rkc = p.lr_mode == 3 ? 32 * ((p.lr_rp + 31) / 32) : (p.lr_mode == 2 ? 32 : 0);
     for (const auto& w : W8LR) {
-      const int bm = w[1], bn = w[2], bn_eff = lr2 ? bn - 32 : bn;
+      const int bm = w[1], bn = w[2], bn_eff = bn - rkc;
+      if (bn_eff < 32) continue;
       int steps[4], nsteps = 0;
       auto add = [&](int st) {
         if (st <= 0 || st > bn_eff) return;
@@ -1862,10 +1883,10 @@ int check_gemm(const T2VGemm& p) {
     T2V_CHECK_ARG(p.b_trans && !p.b_conv && p.a_mode == T2V_A_CONV && p.K == p.geom.KH * p.geom.KW * p.geom.C,
                   "t2v_gemm: b_tapflip needs b_trans=1 and a conv gather on A");
   if (p.lr_mode != 0) {
-    T2V_CHECK_ARG(p.lr_mode == 1 || p.lr_mode == 2, "t2v_gemm: lr_mode must be 0, 1 or 2");
+    T2V_CHECK_ARG(p.lr_mode >= 1 && p.lr_mode <= 3, "t2v_gemm: lr_mode must be 0, 1, 2 or 3");
     T2V_CHECK_ARG(!p.a_trans && !p.b_trans && p.batch <= 1 && p.split_k <= 1 && p.out_mode == T2V_OUT_BF16 && p.drop_p == 0.f && (p.N & 7) == 0,
                   "t2v_gemm: a rank-wide epilogue term needs a plain NN launch with bf16 output");
-    T2V_CHECK_ARG(p.lr_b && ((uintptr_t)p.lr_b & 15) == 0 && (p.lr_mode == 2 || (p.lr_a && ((uintptr_t)p.lr_a & 15) == 0)),
+    T2V_CHECK_ARG(p.lr_b && ((uintptr_t)p.lr_b & 15) == 0 && (p.lr_mode != 1 || (p.lr_a && ((uintptr_t)p.lr_a & 15) == 0)),
                   "t2v_gemm: lr_a / lr_b must be 16-byte aligned");
   }
   return T2V_OK;
@@ -1927,6 +1948,16 @@ extern "C" int t2v_gemm_lr_ok(const T2VGemm* pp) {
   if (!pp || pp->lr_mode == 0) return 0;
   T2VGemm p = *pp;
   if (check_gemm(p) != T2V_OK || !w8_ok(p) || p.alpha != 1.f) return 0;
+  if (p.lr_mode == 3) {
+    // dt = (mask dy / (1-p)) U^T computed by the backward-data launch itself: dense A, up to 64 ranks (two fragments), the members
+    // of a projection group partition K in whole 64-deep stages, the mask matrix within 2^34 elements (32-bit quad index)
+    if (p.lr_rp < 8 || p.lr_rp > 64 || p.lr_rp % 8 != 0 || p.a_mode != T2V_A_DENSE || p.n_split > 0 || p.N < 32 || p.lr_scale != 1.f) return 0;
+    if (!p.B2 || !p.D2 || p.ldb2 % 8 != 0 || p.ldd2 % 8 != 0 || p.ldd2 < p.lr_rp || p.lr_taps > 1 || p.b2_klen > 0) return 0;
+    if (p.lr_group_cols != 0 && (p.lr_group_cols % 64 != 0 || p.K % p.lr_group_cols != 0 || p.K / p.lr_group_cols > 3)) return 0;
+    if ((long long)p.M * (p.lr_group_cols > 0 ? p.lr_group_cols : p.K) >= (1ll << 34)) return 0;
+    if ((long long)p.N * p.lr_ldb >= 0x7ff00000ll || (long long)p.lr_rp * p.ldb2 * 2 >= 0x7ff00000ll || (long long)p.M * p.ldd2 >= 0x7ff00000ll) return 0;
+    return 1;
+  }
   if (p.lr_rp < 8 || p.lr_rp > (p.lr_mode == 1 ? 48 : 32) || p.lr_rp % 8 != 0) return 0;
   if (p.lr_group_cols != 0 && (p.lr_mode != 2 || p.lr_group_cols % 32 != 0 || p.N % p.lr_group_cols != 0 || p.N / p.lr_group_cols > 3)) return 0;
   if (p.lr_mode == 2 && (p.N < 32 || p.n_split > 0)) return 0;

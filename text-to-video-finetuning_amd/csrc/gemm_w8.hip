@@ -38,6 +38,9 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "colsum.h"
+#ifndef W8_PART
+#define W8_PART 0
+#endif
 
 namespace {
 
@@ -72,12 +75,49 @@ struct EpiPlan {
   static_assert(WM % WRP == 0 && FM % FG == 0 && BYTES <= LDS_MAX, "staging plan");
 };
 
+// mode 3 (LR = 2): zero the dropped elements of an A fragment chunk — eight consecutive K elements of one row = two quads of the
+// dropout protocol (common.h: quad q of the mask matrix [rows, W], index = row * W + k; q < 2^32, checked by launch_w8).  The
+// keep test `field >= thr` of the four 16-bit fields runs two at a time on packed 16-bit lanes: (x -sat (thr - 1)) >= 1.
+typedef unsigned short t2v_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned keep_pair(unsigned x, unsigned thrm1_pk) {
+  t2v_u16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(t2v_u16x2, x), __builtin_bit_cast(t2v_u16x2, thrm1_pk));
+  const t2v_u16x2 one = {1, 1}, all = {0xffff, 0xffff};
+  d = __builtin_elementwise_min(d, one) * all;
+  return __builtin_bit_cast(unsigned, d);
+}
+__device__ __forceinline__ bf16x8 mask_chunk(const bf16x8& a, unsigned q, unsigned s0, unsigned s1, unsigned thrm1_pk) {
+  const DropKey k{s0, s1, 0u};
+  const DropQuad h0 = drop_quad(k, (unsigned long long)q), h1 = drop_quad(k, (unsigned long long)(q + 1u));
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 w = __builtin_bit_cast(u32x4, a);
+  w[0] &= keep_pair(h0.a, thrm1_pk);
+  w[1] &= keep_pair(h0.b, thrm1_pk);
+  w[2] &= keep_pair(h1.a, thrm1_pk);
+  w[3] &= keep_pair(h1.b, thrm1_pk);
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+// the same from eight keep bits (bit e = element e of the chunk), read from the forward launch's keep-bit plane (T2VGemm.lr_plane)
+__device__ __forceinline__ bf16x8 mask_chunk_bits(const bf16x8& a, unsigned bits) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 w = __builtin_bit_cast(u32x4, a);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const unsigned lo = (unsigned)(((int)(bits << (31 - 2 * d))) >> 31), hi = (unsigned)(((int)(bits << (30 - 2 * d))) >> 31);
+    w[d] &= (lo & 0xffffu) | (hi & 0xffff0000u);
+  }
+  return __builtin_bit_cast(bf16x8, w);
+}
+
 // CS: the instantiation with the LDS-staged epilogue (column statistics for the GroupNorm fusion need it); the other one
 // stores from registers.  Two kernels instead of a run-time branch: with both epilogues in one body the register allocator
 // spilled in each of them.
 // LR: the instantiation that knows the rank-wide epilogue term (T2VGemm.lr_*: the LoRA branch of a wrapped layer whose dropout
-// is active, folded into the launch) — separate kernels so that the plain ones keep their register allocation.
-template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS, bool LR = false>
+// is active, folded into the launch) — separate kernels so that the plain ones keep their register allocation.  LR = 1: modes
+// 1 and 2; LR = 2: mode 3 (round 6: the backward-data launch of a dropped LINEAR wrapper computes dt = (mask dy / (1-p)) U^T
+// itself — rank fragments at the END of the tile's columns whose MFMAs take a MASKED copy of the A fragments, the mask hashed in
+// the K loop by the one wave column that owns them — and adds s dt D^T in its epilogue: no t2v_lora_drop_dt launch).
+template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS, int LR = 0>
 __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int nstep, const int ntn, const int splits, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(WM * WN * KG == 8 && (KG == 1 || KG == 2), "eight waves: WM x WN x KG");
@@ -96,6 +136,12 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   using Epi = EpiPlan<BN, WM, FM>;
   constexpr int EPI_BYTES = Epi::BYTES;
   constexpr int SMEM_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;      // + 16 bytes for the split-K ticket word
+  // mode 3 with a keep-bit plane: every rank wave keeps, per ring stage, the plane words of its own TM rows x the stage's two
+  // 32-column fragments (TM * 8 bytes) in a slot of its own behind the ring — filled by the wave's OWN LDS-DMA next to the stage's
+  // operand pieces and read back only by that wave (its covering vmcnt is the only ordering needed)
+  constexpr int NMK = TM / 32;                                      // mask DMA instructions per stage and rank wave (256 B each)
+  constexpr int MASK_OFF = SMEM_BYTES + 16, MASK_SLOT = TM * 8;
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   warm_kernargs<(int)sizeof(T2VGemm) + 16>();        // (common.h)
@@ -140,13 +186,20 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   const int n0 = tn * nstep;
   // lr_mode 2: the tile = nbase base columns, padded to whole fragments, + one fragment of rank columns (the lr_rp rows of B2:
   // t = x (*) D^T is computed by EVERY column tile for its own epilogue)
-  const bool lr2 = LR && p.lr_mode == 2;
-  const int nbase = lr2 ? min(N - n0, nstep) : min(N - n0, tn == ntn - 1 ? BN : nstep);
+  const bool lr2 = LR == 1 && p.lr_mode == 2;
+  constexpr bool lr3 = LR == 2;
+  // mode 3: nrf fragments of rank columns (the lr_rp rows of B2 = U, rank-major) occupy the LAST 32 nrf columns of the tile,
+  // i.e. the last fragments of the last wave column — a static position, so that the K loop knows at compile time which MFMAs
+  // take the masked A fragments
+  const int nrf = lr3 ? (p.lr_rp + 31) >> 5 : 0;
+  const int rk3 = BN - 32 * nrf;
+  const bool rankwave = lr3 && (wave / (WM * KG)) == WN - 1;
+  const int nbase = (lr2 || lr3) ? min(N - n0, nstep) : min(N - n0, tn == ntn - 1 ? BN : nstep);
   const int rk0 = lr2 ? ((nbase + 31) & ~31) : 0x40000000;           // tile-local column of the rank fragment
   // projection group (lr_group_cols > 0): the tile belongs to member n0 / lr_group_cols (launch_w8: the column step divides it)
   const int gcols = (lr2 && p.lr_group_cols > 0) ? p.lr_group_cols : 0;
   const int member = gcols ? n0 / gcols : 0;
-  const int ncols = lr2 ? rk0 + 32 : nbase;                          // columns this tile owns (multiple of 8)
+  const int ncols = lr2 ? rk0 + 32 : ((lr3 && rankwave) ? BN : nbase);     // columns this tile owns (multiple of 8)
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
 
@@ -200,7 +253,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x80000000u, 0x00020000);
   __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x80000000u, 0x00020000);
   __amdgpu_buffer_rsrc_t srdB2 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((p.n_split > 0 || (LR && p.lr_mode == 2)) ? p.B2 : p.B), 0, 0x80000000u, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)((p.n_split > 0 || lr2 || lr3) ? p.B2 : p.B), 0, 0x80000000u, 0x00020000);
   if (is_conv) {
     conv_rows();
   } else {
@@ -225,10 +278,54 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       row = (unsigned)(second ? nl - rk0 + member * p.lr_rp : n);
       rok = second ? (nl - rk0 < p.lr_rp) : (nl < nbase);
     }
+    if (lr3) {                                     // (rk3 and nbase are multiples of 8 = WROWS: wave-uniform side)
+      second = (wave * WROWS + RPP * i) >= rk3;
+      row = (unsigned)(second ? nl - rk3 : n);
+      rok = second ? (nl - rk3 < p.lr_rp) : (nl < nbase);
+    }
     if (second) b2lane |= 1u << i;
     vb[i] = rok ? (row * (unsigned)(second ? p.ldb2 : p.ldb) + (unsigned)kc * 8u) * 2u : OOB;   // rows past the tile: zeros, no fetch
   }
 
+  // ---- mode 3, keep-bit plane: the rank waves fetch their mask words with the stage (see MASK_OFF above)
+  const bool m_pl = lr3 && rankwave && p.lr_plane != nullptr && p.lr_drop_p > 0.f;
+  __amdgpu_buffer_rsrc_t srdP = __builtin_amdgcn_make_buffer_rsrc((void*)(m_pl ? p.lr_plane : p.B), 0, 0x80000000u, 0x00020000);
+  unsigned vpm[NMK];                               // per-lane byte offset of (fragment, row) inside the stage's plane words
+  int lk_w = 0x3fffffff;                           // K width of a mask member (the loader runs ahead of the compute)
+  unsigned lk_bytes = 0;                           // bytes of one member's plane
+  const int rwid = (wave % (WM * KG));             // rank wave id: wr + WM * kg
+#pragma unroll
+  for (int f = 0; f < NMK; ++f) vpm[f] = OOB;
+  if constexpr (lr3) {
+    if (m_pl) {
+      const int W = p.lr_group_cols > 0 ? p.lr_group_cols : p.K;
+      lk_w = W;
+      lk_bytes = (unsigned)(((long long)M * W) >> 3);
+      // TM = 32: one instruction, lanes 0-31 = fragment 0 / lanes 32-63 = fragment 1 of rows 0..31; TM = 64: instruction f =
+      // fragment f, lane = row
+#pragma unroll
+      for (int f = 0; f < NMK; ++f) {
+        const int r = NMK == 1 ? (lane & 31) : lane, fr = NMK == 1 ? (lane >> 5) : f;
+        const long long m = m0 + wr * TM + r;
+        vpm[f] = m < M ? (unsigned)(((long long)fr * M + m) * 4) : OOB;
+      }
+    }
+  }
+  auto issue_mask = [&](int k0, int stage) {
+    if constexpr (lr3) {
+      const int lmem = (k0 >= lk_w ? 1 : 0) + (k0 >= 2 * lk_w ? 1 : 0);      // (uniform) member of the projection group
+      const unsigned so = (unsigned)lmem * lk_bytes + (unsigned)((k0 - lmem * lk_w) >> 5) * (unsigned)M * 4u;
+      unsigned char* dst = smem + MASK_OFF + (rwid * NSTAGE + stage) * MASK_SLOT;
+#pragma unroll
+      for (int f = 0; f < NMK; ++f) {
+        if (NMK == 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srdP, (__attribute__((address_space(3))) void*)(dst + lane * 4), 4, (int)vpm[0], (int)so, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srdP, (__attribute__((address_space(3))) void*)(dst + f * 256 + lane * 4), 4, (int)vpm[f],
+                                                   (int)so, 0, 0);      // (vpm[f] carries the fragment's f * M words)
+      }
+    }
+  };
   // pieces [lo, hi) of the LPT per-thread LDS-DMA loads of one stage (A passes first); the phased schedules spread a stage
   // over several phases.  advance_window() after the stage's last A piece.
   auto issue_pieces = [&](int k0, int stage, int lo, int hi) {
@@ -251,6 +348,9 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
                                                  (__attribute__((address_space(3))) void*)(sB + (tid + NT * ib) * 16), 16, (int)vo,
                                                  (second ? k0 - wlo : k0) * 2, 0, 0);
       }
+    }
+    if constexpr (lr3) {
+      if (m_pl && hi >= LPT && lo < LPT) issue_mask(k0, stage);     // (with the stage's last operand piece: LPT + NMK loads per stage)
     }
   };
   auto advance_window = [&]() {
@@ -299,9 +399,40 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   // column fragments of this wave that hold columns of the tile
   const int nfw = max(0, min(FN, (ncols - wc * TN + 31) >> 5));
 
+  // ---- mode 3: mask state of the wave column that owns the rank fragments.  The mask of member i (a projection group's members
+  // partition K; a layer of its own is one member spanning K) is the one its forward launch drew: seed i, row width W, column
+  // k - i W — the matrix t2v_lora_drop_dt regenerated.  Keys of up to three members live in scalar registers; the K loop walks K
+  // monotonically, so the current member advances by comparison (no division per step).
+  unsigned mk_s0[3] = {0, 0, 0}, mk_s1[3] = {0, 0, 0}, mk_thr = 0;
+  unsigned rowq[FM];
+  int m_w = 0x3fffffff;                            // K width of a mask member (>= K: one member)
+  bool m_on = false;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) rowq[i] = 0;
+  if constexpr (lr3) {
+    if (rankwave && p.lr_drop_p > 0.f) {
+      m_on = true;
+      const int W = p.lr_group_cols > 0 ? p.lr_group_cols : p.K;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        if (m_pl) continue;                          // (keep bits come from the forward launch's plane: no keys)
+        const DropKey dk = drop_key(eff_seed(m == 0 ? p.lr_drop_seed : p.lr_group_seed[m - 1], p.drop_epoch), p.lr_drop_p);
+        mk_s0[m] = dk.s0;
+        mk_s1[m] = dk.s1;
+        mk_thr = (dk.thr - 1u) * 0x00010001u;       // (thr >= 1 for p > 0)
+      }
+      m_w = W;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        rowq[i] = (unsigned)(((unsigned long long)((unsigned)m0 + wr * TM + i * 32 + (lane & 31)) * (unsigned)W) >> 2);
+    }
+  }
   if (dbg & 8) tl[1] = __builtin_readcyclecounter();
-  auto kloop = [&](auto nf_tag) {
+  auto kloop = [&](auto nf_tag, auto rk_tag) {
     constexpr int NF = decltype(nf_tag)::value;
+    constexpr int RK = decltype(rk_tag)::value;      // 1 / 2: this wave owns the rank fragments of a mode-3 tile (NF == FN) and
+                                                     // hashes the mask (1) / reads the forward launch's keep-bit plane (2)
+    constexpr int LW = LPT + (RK == 2 ? NMK : 0);    // loads this wave issues per stage (counted waits)
     auto load_frags = [&](bf16x8(&af)[FM], bf16x8(&bfr)[FN], int stage, int kk) {
       const unsigned char* sA = smem + stage * STAGE;
       const unsigned char* sB = sA + A_BYTES;
@@ -311,7 +442,45 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
       for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(sB + brow + j * (32 * ROWB) + ko);
     };
-    auto mfma = [&](const bf16x8(&af)[FM], const bf16x8(&bfr)[FN]) {
+    auto mfma = [&](const bf16x8(&af)[FM], const bf16x8(&bfr)[FN], int kq, int cstage) {
+      if constexpr (RK != 0) {
+        // kq = K index of this k16 step: the lane's chunk holds k = kq + 8 (lane >> 5) .. + 7 of its row.  Straight-line code only:
+        // uniform branches around single MFMAs made the compiler copy accumulators and pad with s_nop (round 6, first version) —
+        // the member index comes from two compares, the operand of fragment FN - 2 from a select.
+        const int mem = (kq >= m_w ? 1 : 0) + (kq >= 2 * m_w ? 1 : 0);      // (m_w >= K for a layer of its own: always 0)
+        const unsigned kk = (unsigned)(kq - mem * m_w);                      // member-local k (members span whole 64-deep stages)
+        bf16x8 maf[FM];
+        if constexpr (RK == 2) {
+          const unsigned char* ms = smem + MASK_OFF + (rwid * NSTAGE + cstage) * MASK_SLOT + ((kk >> 5) & 1u) * (TM * 4) + (lane & 31) * 4;
+          const unsigned sh = 4u * (((kk & 31u) >> 3) + (unsigned)(lane >> 5));
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const unsigned w = *(const unsigned*)(ms + i * 128);
+            maf[i] = mask_chunk_bits(af[i], ((w >> sh) & 0xfu) | (((w >> (16u + sh)) & 0xfu) << 4));
+          }
+        } else {
+          const unsigned s0 = mem == 0 ? mk_s0[0] : (mem == 1 ? mk_s0[1] : mk_s0[2]);
+          const unsigned s1 = mem == 0 ? mk_s1[0] : (mem == 1 ? mk_s1[1] : mk_s1[2]);
+          const unsigned kl4 = (kk + 8u * (unsigned)(lane >> 5)) >> 2;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const bf16x8 mk = mask_chunk(af[i], rowq[i] + kl4, s0, s1, mk_thr);
+            maf[i] = m_on ? mk : af[i];
+          }
+        }
+        // fragment FN - 2 is a rank fragment only with two of them (a projection group's 48 .. 64 ranks); its B rows outside the
+        // current member's K range are zero, so both fragments simply multiply at every step
+        bf16x8 a2[FM];
+        const bool two = nrf == 2;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a2[i] = two ? maf[i] : af[i];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < NF; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], j == FN - 1 ? maf[i] : (j == FN - 2 ? a2[i] : af[i]), acc[i][j], 0, 0, 0);
+        return;
+      }
       if (dbg & 2) {                                 // ablation (T2V_W8_DBG=2): fragments stay live, no matrix work
 #pragma unroll
         for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[i]));
@@ -338,8 +507,8 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       int stage = 0;
       for (int it = 0; it < nt; ++it) {
         const int ahead = min(nt, it + NSTAGE - 1) - (it + 1);
-        if (ahead >= 2) wait_vmcnt<2 * LPT>();
-        else if (ahead == 1) wait_vmcnt<LPT>();
+        if (ahead >= 2) wait_vmcnt<2 * LW>();
+        else if (ahead == 1) wait_vmcnt<LW>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if ((dbg & 8) && it == 0) tl[2] = __builtin_readcyclecounter();
@@ -355,7 +524,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           }
           bf16x8 af[FM], bfr[FN];
           load_frags(af, bfr, stage, kg * KS + j);
-          mfma(af, bfr);
+          mfma(af, bfr, kbeg + it * BKT + (kg * KS + j) * 16, stage);
         }
         if (++stage == NSTAGE) stage = 0;
       }
@@ -369,8 +538,8 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       constexpr int PP = (LPT + NP - 1) / NP;
       {
         const int ahead = min(nt, NSTAGE) - 1;
-        if (ahead >= 2) wait_vmcnt<2 * LPT>();
-        else if (ahead == 1) wait_vmcnt<LPT>();
+        if (ahead >= 2) wait_vmcnt<2 * LW>();
+        else if (ahead == 1) wait_vmcnt<LW>();
         else wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
@@ -392,15 +561,15 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
               pend = false;
             }
           }
-          if (j & 1) mfma(af1, bf1);
-          else mfma(af0, bf0);
+          if (j & 1) mfma(af1, bf1, kbeg + it * BKT + (kg * KS + j) * 16, stage);
+          else mfma(af0, bf0, kbeg + it * BKT + (kg * KS + j) * 16, stage);
         }
         int nstage = stage + 1;
         if (nstage == NSTAGE) nstage = 0;
         if (it + 1 < nt) {
           wait_lgkm0();                                     // this wave is done reading `stage`
           // stage it+1 landed; what may stay in flight: the stages behind it (NSTAGE = 3: stage it+2)
-          if (NSTAGE >= 3 && it + 2 < nt) wait_vmcnt<LPT>();
+          if (NSTAGE >= 3 && it + 2 < nt) wait_vmcnt<LW>();
           else wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();                     // stage it+1 visible to every wave; `stage` is free
           if (it + NSTAGE < nt) {
@@ -411,7 +580,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           }
           load_frags(af0, bf0, nstage, kg * KS);
         }
-        mfma(af1, bf1);                                     // last k16 step of the stage (KS even: it sits in set 1)
+        mfma(af1, bf1, kbeg + it * BKT + (kg * KS + KS - 1) * 16, stage);     // last k16 step of the stage (KS even: it sits in set 1)
         stage = nstage;
       }
     } else if constexpr (SCHED == 2) {
@@ -456,7 +625,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           phase_barrier();
           // ---- C phase
           __builtin_amdgcn_s_setprio(1);
-          mfma(af, bfr);
+          mfma(af, bfr, 0, 0);
           __builtin_amdgcn_s_setprio(0);
           if (j == KS - 1 && grp == 0) stage_wait();
           phase_barrier();
@@ -505,7 +674,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         // ---- C(it, 0)
         load_frags(af1, bf1, stage, kg * KS + 1);
         __builtin_amdgcn_s_setprio(1);
-        mfma(af0, bf0);
+        mfma(af0, bf0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         if (grp == 1 && it + 1 < nt) {                        // g1: stage it+1 landed (its own pieces), one phase early
           if (steady) wait_vmcnt<(NSTAGE - 3) * LPT + PP>();
@@ -526,7 +695,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         // ---- C(it, 1)
         if (it + 1 < nt) load_frags(af0, bf0, nstage, kg * KS);
         __builtin_amdgcn_s_setprio(1);
-        mfma(af1, bf1);
+        mfma(af1, bf1, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         phase_barrier();
         stage = nstage;
@@ -534,9 +703,12 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       if (grp == 0) __builtin_amdgcn_s_barrier();
     }
   };
-  if (nfw >= FN) kloop(std::integral_constant<int, FN>{});
-  else if (FN >= 2 && nfw == FN - 1) kloop(std::integral_constant<int, (FN >= 2 ? FN - 1 : FN)>{});
-  else kloop(std::integral_constant<int, (FN >= 3 ? FN - 2 : (FN >= 2 ? FN - 1 : FN))>{});
+  using NoRank = std::integral_constant<int, 0>;
+  if (lr3 && rankwave && m_pl) kloop(std::integral_constant<int, FN>{}, std::integral_constant<int, lr3 ? 2 : 0>{});
+  else if (lr3 && rankwave) kloop(std::integral_constant<int, FN>{}, std::integral_constant<int, lr3 ? 1 : 0>{});
+  else if (nfw >= FN) kloop(std::integral_constant<int, FN>{}, NoRank{});
+  else if (FN >= 2 && nfw == FN - 1) kloop(std::integral_constant<int, (FN >= 2 ? FN - 1 : FN)>{}, NoRank{});
+  else kloop(std::integral_constant<int, (FN >= 3 ? FN - 2 : (FN >= 2 ? FN - 1 : FN))>{}, NoRank{});
 
   wait_vmcnt<0>();
   __syncthreads();                                 // ring idle: reuse it as the epilogue staging buffer
@@ -630,20 +802,89 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
     for (int io = 0; io < NB; ++io) rowg[io] = (unsigned)m0 + wr * TM + (ib0_ + io) * 32 + l31;
     auto col0_of = [&](int j) { return wc * TN + j * 32; };
+    if constexpr (LR == 2) {
+      // ---- mode 3: dt = (mask dy / (1-p)) U^T of this tile's rows sits, complete, in the rank fragments of the last wave column
+      // (fragments FN - nrf .. FN - 1).  As in mode 2 the transposed accumulator's register order — registers 8s .. 8s+7 of a
+      // lane = ranks 32f + 16s + {4h .. 4h+3, 8+4h .. 8+4h+3} of tile row (lane & 31) — is used as the k order of the product
+      // with LB = (s D)^T, which is read in the same permuted order: 16-rank chunk c = 2f + s, up to four of them.
+      const int nkc = (rp + 15) >> 4;
+      const float inv = p.lr_drop_p > 0.f ? 1.f / (1.f - p.lr_drop_p) : 1.f;
+      bf16x8* xt = (bf16x8*)smem;                    // [WM * FM bands][4 chunks][64 lanes]
+      if (KG == 2) __syncthreads();                  // (the K-group exchange's reads of this LDS are over)
+      if (rankwave) {
+#pragma unroll
+        for (int jj = FN - 2; jj < FN; ++jj) {
+          const int f = jj - (FN - nrf);
+          if (f < 0) continue;
+#pragma unroll
+          for (int io = 0; io < NB; ++io)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int c = 2 * f + ks;
+              if (c >= nkc) continue;
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = acc[io][jj][8 * ks + e] * inv;
+              const bf16x8 tv = pack8bf(v);
+              xt[((wr * FM + ib0_ + io) * 4 + c) * 64 + lane] = tv;
+              if (tn == 0 && rowg[io] < (unsigned)M) {        // (first column tile) dt for the factor gradient dD
+                bf16_t* tp = (bf16_t*)p.D2 + rowg[io] * (unsigned)p.ldd2 + 16 * c + 4 * half;
+                const bf16x4 lo = {tv[0], tv[1], tv[2], tv[3]}, hi = {tv[4], tv[5], tv[6], tv[7]};
+                if (16 * c + 4 * half < rp) *(bf16x4*)tp = lo;
+                if (16 * c + 8 + 4 * half < rp) *(bf16x4*)(tp + 8) = hi;
+              }
+            }
+        }
+      }
+      __syncthreads();
+      bf16x8 la3[NB][4];
+#pragma unroll
+      for (int io = 0; io < NB; ++io)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) la3[io][c] = c < nkc ? xt[((wr * FM + ib0_ + io) * 4 + c) * 64 + lane] : zero8;
+      if constexpr (CS) __syncthreads();             // (the staging passes reuse this LDS)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if (col0_of(j) >= nbase) continue;           // padding, rank fragments
+        const bool cok = col0_of(j) + l31 < nbase;
+        const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + 4 * half;
+        bf16x8 lb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bf16x4 lo = (cok && c < nkc) ? *(const bf16x4*)(lbp + 16 * c) : zero4;
+          const bf16x4 hi = (cok && c < nkc) ? *(const bf16x4*)(lbp + 16 * c + 8) : zero4;
+          lb[c] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int io = 0; io < NB; ++io)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < nkc) acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[c], la3[io][c], acc[io][j], 0, 0, 0);
+      }
+      return;
+    } else {
+    // (mode 2) keep-bit plane for the backward-data launch of the same layer (T2VGemm.lr_plane, fragment-major: the lane's 16 keep
+    // bits of a fragment are one 16-bit word; a wave's 64 words of a fragment are one 128-byte line)
+    unsigned short* plane = (masked && lr2 && p.lr_plane) ? (unsigned short*)((unsigned char*)p.lr_plane + (size_t)member * (((size_t)M * mwidth) >> 3)) : nullptr;
     auto finish = [&](int io, int j, const f32x16& tmp) {       // acc += sc * mask * tmp
+      unsigned pw = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float t0 = sc * tmp[4 * q], t1 = sc * tmp[4 * q + 1], t2 = sc * tmp[4 * q + 2], t3 = sc * tmp[4 * q + 3];
         if (masked) {
           const unsigned long long idx = (unsigned long long)rowg[io] * mwidth + (unsigned)(mcol0 + col0_of(j) + 8 * q + 4 * half);
           const DropQuad h = drop_quad(dkey, idx >> 2);
-          t0 = (h.a & 0xffffu) >= dkey.thr ? t0 : 0.f;
-          t1 = (h.a >> 16) >= dkey.thr ? t1 : 0.f;
-          t2 = (h.b & 0xffffu) >= dkey.thr ? t2 : 0.f;
-          t3 = (h.b >> 16) >= dkey.thr ? t3 : 0.f;
+          const bool k0 = (h.a & 0xffffu) >= dkey.thr, k1 = (h.a >> 16) >= dkey.thr, k2 = (h.b & 0xffffu) >= dkey.thr, k3 = (h.b >> 16) >= dkey.thr;
+          t0 = k0 ? t0 : 0.f;
+          t1 = k1 ? t1 : 0.f;
+          t2 = k2 ? t2 : 0.f;
+          t3 = k3 ? t3 : 0.f;
+          pw |= ((k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u)) << (4 * q);
         }
         acc[io][j][4 * q] += t0; acc[io][j][4 * q + 1] += t1; acc[io][j][4 * q + 2] += t2; acc[io][j][4 * q + 3] += t3;
       }
+      if (plane && rowg[io] < (unsigned)M)
+        plane[(((size_t)((mcol0 + col0_of(j)) >> 5) * (size_t)M + rowg[io]) << 1) + half] = (unsigned short)pw;
     };
     if (lr2) {
       // this tile's t = x (*) D^T sits in the accumulators of the rank fragment (wave column wc_r, fragment j_r): registers
@@ -776,6 +1017,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
       }
     }
+    }
   };
 
   // ---- register epilogue (every launch without column statistics): no staging through LDS.  The transposed accumulators give
@@ -824,7 +1066,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
       };
       Pre cur, nxt;
-      if (KG == 2 && role == 0 && !LR) prefetch(0, cur);      // (in flight under the K-group exchange)
+      if (KG == 2 && role == 0 && LR == 0) prefetch(0, cur);      // (in flight under the K-group exchange)
       if constexpr (KG == 2) {
         constexpr int PER = OWN * FN * 4 * 64;        // float4 slots per (receiving group, wave pair)
         float4* X = (float4*)smem;
@@ -912,11 +1154,11 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         }
       }
       if (!writer) {
-        if constexpr (LR) {
+        if constexpr (LR != 0) {
           // (after the K-group exchange and the split-K reduction: the accumulators are complete — mode 2 multiplies them)
           if (p.lr_mode != 0) rank_phase(ib0, std::integral_constant<int, OWN>{});
         }
-        if (KG == 1 || role != 0 || LR) prefetch(0, cur);    // (the slab reduction / the rank phase need the registers)
+        if (KG == 1 || role != 0 || LR != 0) prefetch(0, cur);    // (the slab reduction / the rank phase need the registers)
 #pragma unroll
         for (int ch = 0; ch < 2 * OWN * FN; ++ch) {      // chunk = (fragment, quad pair)
           const int io = (ch >> 1) / FN, j = (ch >> 1) % FN, qp = 2 * (ch & 1);
@@ -991,7 +1233,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   }
   // ---- column statistics of the stored tile (T2VGemm.colsum, GroupNorm fusion): every thread accumulates its 8 columns over
   // the rows it writes; the RPI threads of a column chunk are combined in fixed order through LDS after the last pass
-  if constexpr (LR) {
+  if constexpr (LR != 0) {
     // staged path: the term is added to ONE of the partial sums that meet later (K group 0 of split 0); mode 2 needs complete
     // accumulators and therefore KG == 1 and a single split (launch_w8)
     if (p.lr_mode != 0 && (KG == 1 || kg == 0) && bz == 0) rank_phase(0, std::integral_constant<int, FM>{});
@@ -1160,19 +1402,40 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS, bool LR = false>
+template <int BM, int BN, int WM, int WN, int KG, int NSTAGE, int SCHED, int BKT, bool CS, int LR = 0>
 int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   constexpr int RING = NSTAGE * (BM + BN) * BKT * 2;
   constexpr int EPI = EpiPlan<BN, WM, BM / WM / 32>::BYTES;
-  constexpr int SMEM = (RING > EPI ? RING : EPI) + 16;
+  // (LR = 2: + the rank waves' keep-bit plane slots, see MASK_OFF in the kernel)
+  constexpr int SMEM = (RING > EPI ? RING : EPI) + 16 + (LR == 2 ? WM * KG * NSTAGE * (BM / WM) * 8 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   T2V_CHECK_ARG(!(p.colsum && p.cs_mode == 2) || (!p.R && p.cs_x && p.cs_sums && p.cs_gamma && p.cs_beta && p.cs_G > 0 &&
                                                    p.cs_domain_rows % BM == 0 && p.cs_ldx % 8 == 0),
                 "t2v_gemm_w8: colsum mode 2 needs x / sums / gamma / beta, no residual, and tiles inside a domain");
   T2V_CHECK_ARG(p.n_split <= 0 || p.n_split % (64 / (BKT / 8)) == 0,
                 "t2v_gemm_w8: n_split=%d must be a multiple of %d for this configuration", p.n_split, 64 / (BKT / 8));
-  const bool lr2 = LR && p.lr_mode == 2;
-  if constexpr (LR) {
+  const bool lr2 = LR == 1 && p.lr_mode == 2;
+  const bool lr3 = LR == 2;
+  if constexpr (LR == 2) {
+    T2V_CHECK_ARG(p.lr_mode == 3, "t2v_gemm_w8: lr_mode %d on a mode-3 kernel", p.lr_mode);
+    T2V_CHECK_ARG(p.lr_rp >= 8 && p.lr_rp <= 64 && p.lr_rp % 8 == 0 && p.lr_b && p.lr_ldb % 8 == 0 && p.alpha == 1.f && p.lr_scale == 1.f,
+                  "t2v_gemm_w8: lr_mode 3 needs a padded rank of 8..64, lr_b (scale folded in) and alpha == lr_scale == 1");
+    T2V_CHECK_ARG(p.a_mode == T2V_A_DENSE && p.n_split <= 0 && p.B2 && p.D2 && p.ldb2 % 8 == 0 && p.ldd2 % 8 == 0 && p.ldd2 >= p.lr_rp &&
+                      p.lr_taps <= 1 && p.b2_klen <= 0,
+                  "t2v_gemm_w8: lr_mode 3 takes a dense A, the up factor (rank-major) in B2 and dt in D2, n_split = 0");
+    T2V_CHECK_ARG(p.lr_drop_p >= 0.f && p.lr_drop_p < 1.f, "t2v_gemm_w8: lr_drop_p must be in [0, 1)");
+    T2V_CHECK_ARG(p.lr_group_cols == 0 || (p.lr_group_cols % 64 == 0 && p.K % p.lr_group_cols == 0 && p.K / p.lr_group_cols <= 3),
+                  "t2v_gemm_w8: lr_group_cols (mode 3: the members' K width) must divide K into at most 3 members of whole stages");
+    T2V_CHECK_ARG((long long)p.M * (p.lr_group_cols > 0 ? p.lr_group_cols : p.K) < (1ll << 34), "t2v_gemm_w8: mask matrix beyond 2^34 elements");
+    T2V_CHECK_ARG((long long)p.N * p.lr_ldb < 0x7ff00000ll && (long long)p.lr_rp * p.ldb2 * 2 < 0x7ff00000ll && (long long)p.M * p.ldd2 < 0x7ff00000ll,
+                  "t2v_gemm_w8: lr_mode 3 offsets");
+    T2V_CHECK_ARG(KG == 1 || !CS, "t2v_gemm_w8: lr_mode 3 with column statistics needs a configuration without K groups");
+    T2V_CHECK_ARG(BN - 32 * ((p.lr_rp + 31) / 32) >= 32, "t2v_gemm_w8: tile too narrow for the rank fragments");
+    T2V_CHECK_ARG(!p.lr_plane || ((p.lr_group_cols > 0 ? p.lr_group_cols : p.K) % 64 == 0 && ((uintptr_t)p.lr_plane & 3) == 0 &&
+                                  (long long)p.M * p.K / 8 < 0x7ff00000ll),
+                  "t2v_gemm_w8: lr_plane (mode 3) needs members of whole 64-column stages and a plane below 2 GiB");
+    if (CS) splits = 1;
+  } else if constexpr (LR == 1) {
     T2V_CHECK_ARG(p.lr_mode == 1 || p.lr_mode == 2, "t2v_gemm_w8: lr_mode %d", p.lr_mode);
     T2V_CHECK_ARG(p.lr_rp >= 8 && p.lr_rp <= (p.lr_mode == 1 ? 48 : 32) && p.lr_rp % 8 == 0 && p.lr_b && p.lr_ldb % 8 == 0 && p.alpha == 1.f,
                   "t2v_gemm_w8: rank-wide epilogue term needs a padded rank of 8..32 (mode 1: ..48), lr_b and alpha == 1");
@@ -1195,6 +1458,8 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
       T2V_CHECK_ARG(p.n_split <= 0 && p.B2 && p.D2 && p.ldb2 % 8 == 0 && p.ldd2 % 8 == 0 && p.ldd2 >= p.lr_rp && p.lr_taps <= 1 && p.b2_klen <= 0,
                     "t2v_gemm_w8: lr_mode 2 takes the down factor in B2 / D2 with n_split = 0");
       T2V_CHECK_ARG((long long)p.lr_rp * 3 * p.ldb2 * 2 < 0x7ff00000ll && (long long)p.M * p.ldd2 < 0x7ff00000ll, "t2v_gemm_w8: lr_mode 2 offsets");
+      T2V_CHECK_ARG(!p.lr_plane || ((p.lr_group_cols > 0 ? p.lr_group_cols : p.N) % 32 == 0 && ((uintptr_t)p.lr_plane & 3) == 0),
+                    "t2v_gemm_w8: lr_plane (mode 2) needs an output width of whole 32-column fragments");
       if (CS) splits = 1;                          // the staged epilogue reduces the splits after the rank phase (t2v_gemm never
                                                    // pairs the two: colsum_bm() answers 0 for a split configuration)
     }
@@ -1212,7 +1477,11 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
   if (nstep <= 0) nstep = BN;
   const int ntm = (p.M + BM - 1) / BM;
   int ntn = 1;
-  if (lr2) {                                       // every tile: up to nstep base columns + one fragment of rank columns
+  if (lr3) {                                       // every tile: up to nstep base columns; the rank fragments sit at the tile's end
+    const int lim = BN - 32 * ((p.lr_rp + 31) / 32);
+    if (nstep > lim) nstep = lim;
+    ntn = (p.N + nstep - 1) / nstep;
+  } else if (lr2) {                                // every tile: up to nstep base columns + one fragment of rank columns
     if (nstep > BN - 32) nstep = BN - 32;
     if (p.lr_group_cols > 0)                       // a tile never straddles two members of a projection group
       while (p.lr_group_cols % nstep != 0) nstep -= 32;
@@ -1244,33 +1513,30 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
 
 // Number of W8 configurations and a pinned-configuration launch (tile table / tuning / diagnostics).  The caller (gemm.hip)
 // has already validated the descriptor and checked that the lean loader and the bf16 epilogue apply.
+#if W8_PART == 0
 extern "C" int t2v_gemm_w8_configs(void) { return 23; }
 // tile rows of a configuration (t2v_gemm_colsum_rows)
 int t2v_gemm_w8_bm(int cfg) {
   static const int bm[] = {128, 128, 256, 128, 128, 256, 128, 256, 256, 128, 256, 128, 128, 256, 128, 128, 128, 128, 256, 128, 128, 128, 128};
   return cfg >= 0 && cfg < (int)(sizeof(bm) / sizeof(bm[0])) ? bm[cfg] : 0;
 }
+#endif
+// The instantiations are spread over three translation units (build_ext.py compiles this file with -DW8_PART=0 / 1 / 2: the
+// plain kernels + the entry points / the LR = 1 kernels (modes 1, 2) / the LR = 2 kernels (mode 3)), so that a rebuild takes the
+// time of the largest third.
+int t2v_gemm_w8_launch_plain(const T2VGemm& p, int cfg, int nstep, int splits, bool staged, hipStream_t s);
+int t2v_gemm_w8_launch_lr(const T2VGemm& p, int cfg, int nstep, int splits, bool staged, hipStream_t s);
+int t2v_gemm_w8_launch_lr3(const T2VGemm& p, int cfg, int nstep, int splits, bool staged, hipStream_t s);
+#if W8_PART == 0
 int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStream_t s) {
   // the staged-epilogue kernels serve the launches that ask for column statistics (and T2V_W8_STAGED=1: A/B runs, tests)
   static const bool force_staged = [] { const char* e = getenv("T2V_W8_STAGED"); return e && atoi(e) != 0; }();
   const bool staged = p.colsum != nullptr || force_staged;
-  if (p.lr_mode != 0) {                            // rank-wide epilogue term: the KG = 1 members of the production set
-    switch (cfg) {
-      case 12: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 4, 64, false, true>(p, nstep, splits, s);
-      case 13: return staged ? launch_w8<256, 256, 4, 2, 1, 2, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<256, 256, 4, 2, 1, 2, 4, 64, false, true>(p, nstep, splits, s);
-      case 17: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 5, 64, false, true>(p, nstep, splits, s);
-      case 18: return staged ? launch_w8<256, 256, 4, 2, 1, 2, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<256, 256, 4, 2, 1, 2, 5, 64, false, true>(p, nstep, splits, s);
-      case 21: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 4, 64, false, true>(p, nstep, splits, s);
-      case 22: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 5, 64, false, true>(p, nstep, splits, s);
-      // K groups: the register epilogue runs the rank phase after the groups have met (mode 2 too); the staged one adds a
-      // mode-1 term to group 0's partial sums
-      case 14: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 4, 64, false, true>(p, nstep, splits, s);
-      case 16: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 4, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 4, 64, false, true>(p, nstep, splits, s);
-      case 19: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 5, 64, false, true>(p, nstep, splits, s);
-      case 20: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 5, 64, true, true>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 5, 64, false, true>(p, nstep, splits, s);
-      default: t2v_set_error("t2v_gemm_w8: configuration %d has no rank-wide epilogue term (12-14, 16-22 do)", cfg); return T2V_EINVAL;
-    }
-  }
+  if (p.lr_mode == 3) return t2v_gemm_w8_launch_lr3(p, cfg, nstep, splits, staged, s);
+  if (p.lr_mode != 0) return t2v_gemm_w8_launch_lr(p, cfg, nstep, splits, staged, s);
+  return t2v_gemm_w8_launch_plain(p, cfg, nstep, splits, staged, s);
+}
+int t2v_gemm_w8_launch_plain(const T2VGemm& p, int cfg, int nstep, int splits, bool staged, hipStream_t s) {
   switch (cfg) {
     //                       BM   BN  WM WN KG NS SCHED BK
     case 0: return launch_w8<128, 384, 2, 2, 2, 2, 0, 64, true>(p, nstep, splits, s);      // wave 64x192, K groups, classic ring
@@ -1308,3 +1574,34 @@ int t2v_gemm_w8_launch(const T2VGemm& p, int cfg, int nstep, int splits, hipStre
     default: t2v_set_error("t2v_gemm_w8: unknown configuration %d", cfg); return T2V_EINVAL;
   }
 }
+#elif W8_PART == 1
+int t2v_gemm_w8_launch_lr(const T2VGemm& p, int cfg, int nstep, int splits, bool staged, hipStream_t s) {   // rank-wide epilogue term: modes 1, 2
+    switch (cfg) {
+      case 12: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 4, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 4, 64, false, 1>(p, nstep, splits, s);
+      case 17: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 5, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 5, 64, false, 1>(p, nstep, splits, s);
+      case 21: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 4, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 4, 64, false, 1>(p, nstep, splits, s);
+      case 22: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 5, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 5, 64, false, 1>(p, nstep, splits, s);
+      // K groups: the register epilogue runs the rank phase after the groups have met (mode 2 too); the staged one adds a
+      // mode-1 term to group 0's partial sums
+      case 14: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 4, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 4, 64, false, 1>(p, nstep, splits, s);
+      case 16: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 4, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 4, 64, false, 1>(p, nstep, splits, s);
+      case 19: return staged ? launch_w8<128, 192, 2, 2, 2, 3, 5, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 192, 2, 2, 2, 3, 5, 64, false, 1>(p, nstep, splits, s);
+      case 20: return staged ? launch_w8<128, 256, 2, 2, 2, 3, 5, 64, true, 1>(p, nstep, splits, s) : launch_w8<128, 256, 2, 2, 2, 3, 5, 64, false, 1>(p, nstep, splits, s);
+      default: t2v_set_error("t2v_gemm_w8: configuration %d has no rank-wide epilogue term (12, 14, 16, 17, 19-22 do; the 256x256 LR kernels spilled and were removed in round 6)", cfg); return T2V_EINVAL;
+    }
+}
+#else
+int t2v_gemm_w8_launch_lr3(const T2VGemm& p, int cfg, int nstep, int splits, bool staged, hipStream_t s) {  // dt computed by the launch itself (mode 3)
+    switch (cfg) {
+      case 12: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 4, 64, true, 2>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 4, 64, false, 2>(p, nstep, splits, s);
+      case 17: return staged ? launch_w8<128, 384, 4, 2, 1, 2, 5, 64, true, 2>(p, nstep, splits, s) : launch_w8<128, 384, 4, 2, 1, 2, 5, 64, false, 2>(p, nstep, splits, s);
+      case 21: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 4, 64, true, 2>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 4, 64, false, 2>(p, nstep, splits, s);
+      case 22: return staged ? launch_w8<128, 384, 2, 4, 1, 2, 5, 64, true, 2>(p, nstep, splits, s) : launch_w8<128, 384, 2, 4, 1, 2, 5, 64, false, 2>(p, nstep, splits, s);
+      case 14: T2V_CHECK_ARG(!staged, "t2v_gemm_w8: lr_mode 3 with column statistics needs a KG = 1 configuration"); return launch_w8<128, 192, 2, 2, 2, 3, 4, 64, false, 2>(p, nstep, splits, s);
+      case 16: T2V_CHECK_ARG(!staged, "t2v_gemm_w8: lr_mode 3 with column statistics needs a KG = 1 configuration"); return launch_w8<128, 256, 2, 2, 2, 3, 4, 64, false, 2>(p, nstep, splits, s);
+      case 19: T2V_CHECK_ARG(!staged, "t2v_gemm_w8: lr_mode 3 with column statistics needs a KG = 1 configuration"); return launch_w8<128, 192, 2, 2, 2, 3, 5, 64, false, 2>(p, nstep, splits, s);
+      case 20: T2V_CHECK_ARG(!staged, "t2v_gemm_w8: lr_mode 3 with column statistics needs a KG = 1 configuration"); return launch_w8<128, 256, 2, 2, 2, 3, 5, 64, false, 2>(p, nstep, splits, s);
+      default: t2v_set_error("t2v_gemm_w8: configuration %d has no lr_mode 3 instantiation (12, 14, 16, 17, 19-22 do)", cfg); return T2V_EINVAL;
+    }
+}
+#endif

@@ -265,6 +265,7 @@ def make_gemm(*, M, N, K, A, lda, B, ldb, D, ldd, a_mode=0, a_trans=0, b_trans=0
         g.lr_group_cols = lr.get("group_cols", 0)
         for i, sd in enumerate(lr.get("group_seeds", ())[:2]):
             g.lr_group_seed[i] = sd
+        g.lr_plane = lr.get("plane")
     if use_ws and out_mode == nv.OUT_BF16 and not a_trans and not b_trans and batch <= 1:
         ws = _gemm_workspace()          # one scratch per (device, stream): stream order serialises its users
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -718,15 +719,24 @@ class _LoraLayer(torch.autograd.Function):
         # descriptor the 8-wave kernels take.
         ctx.prep_ok = _lora_epi and getattr(e, "prep_scale", None) == scale and e.rp <= 32
         kw = None
+        # keep-bit plane (round 6): the forward launch hashes the mask of its output anyway and leaves the bits (M * N / 8 bytes)
+        # for the backward-data launch of a LINEAR wrapper, which then reads them in its K loop instead of hashing again
+        plane = None
+        if (ctx.prep_ok and _lora_plane and drop_p > 0.0 and not conv and npad % 64 == 0 and ctx.needs_input_grad[0] and
+                M >= _LORA_EPI_MIN_ROWS_BWD and _dt_fuse_pays(M, cin_p, npad, e.rp)):
+            plane = torch.empty(M * npad // 8, dtype=torch.uint8, device=x.device)
         if ctx.prep_ok and M >= _LORA_EPI_MIN_ROWS:
             kw = dict(M=M, N=npad, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=npad,
                       a_mode=nv.A_CONV if conv else nv.A_DENSE, geom=cfg.fwd_geom(cin_p) if conv else None,
                       bias=nv.ptr(b32), rowbias=nv.ptr(rowbias), ldrb=_ld(rowbias) if rowbias is not None else 0,
                       rows_per_rb=rpr, R=nv.ptr(residual), ldr=_ld(residual) if residual is not None else 0,
                       B2=e.down_w16.data_ptr(), ldb2=K, D2=t.data_ptr(), ldd2=e.rp,
-                      lr=dict(mode=2, rp=e.rp, b=e.up_t16.data_ptr(), ldb=e.rk, scale=scale, drop_p=drop_p, drop_seed=drop_seed))
+                      lr=dict(mode=2, rp=e.rp, b=e.up_t16.data_ptr(), ldb=e.rk, scale=scale, drop_p=drop_p, drop_seed=drop_seed,
+                              plane=nv.ptr(plane)))
             if not _lr_ok(kw):
                 kw = None
+        if kw is None:
+            plane = None
         if kw is not None:
             _cs_last[0] = launch_gemm(cs={"mode": 1} if colsum else None, **kw)
         else:
@@ -738,6 +748,7 @@ class _LoraLayer(torch.autograd.Function):
             _lowrank_update(y, t, e.up_w16, M, npad, e.rp, scale, drop_p, drop_seed)     # y += s mask (t U^T)
         ctx.cfg, ctx.e, ctx.scale, ctx.drop = cfg, e, scale, (drop_p, drop_seed)
         ctx.has = (rowbias is not None, residual is not None)
+        ctx.plane = plane
         ctx.save_for_backward(x, t, w_base, rowbias)
         return y
 
@@ -768,7 +779,22 @@ class _LoraLayer(torch.autograd.Function):
         dt = torch.empty(M, e.rp, dtype=BF16, device=dy.device)      # dt = g U (unscaled; `scale` is applied by its consumers)
         dx = None
         ride = drop_p == 0.0                         # dt can ride in the dx launch only when both read the same dy
-        if fused_mask:
+        # Round 6 (T2VGemm.lr_mode 3): the backward-data launch of a LINEAR wrapper forms dt itself — rank fragments whose MFMAs
+        # take masked A fragments (the mask hashed in the K loop) — and adds s dt D^T in its epilogue: ONE launch for dx and dt
+        kw3 = None
+        if (fused_mask and need_dx and not conv and ctx.prep_ok and x.shape[0] == M and M >= _LORA_EPI_MIN_ROWS_BWD and
+                _dt_fuse_pays(M, cin_p, npad, e.rp)):
+            wb = prepared_weight(w_base, "bwd")
+            dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
+            kw3 = dict(M=M, N=cin_p, K=wb.shape[1], A=dy.data_ptr(), lda=_ld(dy), B=wb.data_ptr(), ldb=wb.shape[1], D=dx.data_ptr(),
+                       ldd=cin_p, B2=e.up_w16.data_ptr(), ldb2=_ld(e.up_w16), D2=dt.data_ptr(), ldd2=e.rp,
+                       lr=dict(mode=3, rp=e.rp, b=e.down_t16.data_ptr(), ldb=_ld(e.down_t16), drop_p=drop_p, drop_seed=drop_seed,
+                               plane=nv.ptr(ctx.plane)))
+            if not _lr_ok(kw3):
+                kw3, dx = None, None
+        if kw3 is not None:
+            _note_bwd_cs(dx, launch_gemm(cs=_gn_bwd_request(ctx.gn, M, cin_p), **kw3))
+        elif fused_mask:
             nv.call("t2v_lora_drop_dt", dy.data_ptr(), _ld(dy), e.up_w16.data_ptr(), _ld(e.up_w16), dt.data_ptr(), e.rp, M, npad,
                     e.rp, drop_p, drop_seed, nv.stream())
         elif not ride:
@@ -778,7 +804,9 @@ class _LoraLayer(torch.autograd.Function):
         # Epilogue form: dx = dy (*) W^T + s dt (*) D^T in ONE launch — the rank-wide term is a few extra MFMAs per output
         # fragment on operands read straight from memory (dt, the flipped-tap transpose of s D), no pass over dx
         kw = None
-        if (need_dx and not ride and ctx.prep_ok and x.shape[0] == M and M >= _LORA_EPI_MIN_ROWS_BWD and
+        if kw3 is not None:
+            pass
+        elif (need_dx and not ride and ctx.prep_ok and x.shape[0] == M and M >= _LORA_EPI_MIN_ROWS_BWD and
                 (not conv or (_wgrad_window_ok(cfg.fwd_geom(cin_p), M) and cfg.taps() in (1, 3, 9)))):
             wb = prepared_weight(w_base, "bwd")
             dx = torch.empty(M, cin_p, dtype=BF16, device=dy.device)
@@ -788,7 +816,9 @@ class _LoraLayer(torch.autograd.Function):
                               ldb=_ld(e.down_t16)))
             if not _lr_ok(kw):
                 kw, dx = None, None
-        if kw is not None:
+        if kw3 is not None:
+            pass
+        elif kw is not None:
             _note_bwd_cs(dx, launch_gemm(cs=_gn_bwd_request(ctx.gn, M, cin_p), **kw))
         elif need_dx and not conv:
             # linear: [dx | dt] = dy [W^T | U] in ONE launch (dt rides as rp extra output columns)
@@ -838,6 +868,33 @@ class _LoraLayer(torch.autograd.Function):
 
 _drop_fuse = os.environ.get("T2V_DROP_FUSE", "1") != "0"       # A/B switch: masks regenerated inside the backward kernels
 _lora_epi = os.environ.get("T2V_LORA_EPI", "1") != "0"         # A/B switch: the dropped LoRA branch as an epilogue term of the base launch
+_lora_plane = os.environ.get("T2V_LORA_PLANE", "1") != "0"      # A/B switch: keep-bit plane written by the forward launch, read by lr_mode 3
+# dt of a dropped linear wrapper formed by its backward-data launch (lr_mode 3): "0" never, "1" where the estimate below says it pays,
+# "2" wherever the kernels take the descriptor (A/B runs, tests)
+_lora_dt_fuse = int(os.environ.get("T2V_LORA_DT_FUSE", "1") or 0)
+
+
+def _dt_fuse_pays(M, N, K, rp, nmem=1):
+    """Does forming dt inside the backward-data launch (lr_mode 3) beat the separate masked-dt launch?  Measured per signature on
+    the C2 step (profiles/r06_dt_fuse_signatures.txt; in-step microseconds of the backward-data launch without -> with the rank
+    fragments, against the 5.5 - 16 us of the dt launch it replaces): the launch gains one MFMA per A fragment and K step
+    (+9 % at 320 base columns per tile, +20 % at 160) plus ~25 VALU instructions per masked fragment in ONE wave column, which the
+    K loop hides only while it is short —
+      level-0 projections   (32768, 320, K = 320)    +3.5 us  vs 11 us   fused
+      level-1 projections   ( 8192, 640, K = 640)    +0   us  vs  6 us   fused
+      level-0 q/k/v groups  (32768, 320, K = 960)    +5.6 us  vs 16 us   fused
+      level-2 projections   ( 2048, 1280, K = 1280)  +5.7 us  vs 5.5 us  not fused (a wash)
+      deeper groups / K >= 2560 / many column tiles  +11 .. +32 us vs 6 .. 16 us: not fused
+    so: a layer of its own with K <= 640 and N <= 640, or a projection group at M >= 16384."""
+    if _lora_dt_fuse >= 2:
+        return True
+    if _lora_dt_fuse <= 0:
+        return False
+    if nmem > 1:
+        return M >= 16384 and K <= 1024
+    return K <= 640 and N <= 640 and rp <= 32
+
+
 _LORA_EPI_MIN_ROWS = int(os.environ.get("T2V_LORA_EPI_MIN_ROWS", "128"))
 # the same for the backward-data launch (dx = dy (*) W^T + s dt (*) D^T as an epilogue term vs a plain launch + a rank update pass)
 _LORA_EPI_MIN_ROWS_BWD = int(os.environ.get("T2V_LORA_EPI_MIN_ROWS_BWD", "128"))
@@ -1177,10 +1234,15 @@ class _LoraGroupDrop(torch.autograd.Function):
         M = x.shape[0]
         y = torch.empty(M, ncat, dtype=BF16, device=x.device)
         t = torch.empty(M, g.rp, dtype=BF16, device=x.device)
+        plane = None                                   # keep bits of all members (member i at byte i * M * npad_each / 8), see _LoraLayer
+        if (_lora_plane and drop_p > 0.0 and g.npad_each % 64 == 0 and g.rp <= 64 and ctx.needs_input_grad[0] and
+                _dt_fuse_pays(M, K, ncat, g.rp, n)):
+            plane = torch.empty(M * ncat // 8, dtype=torch.uint8, device=x.device)
         launch_gemm(M=M, N=ncat, K=K, A=x.data_ptr(), lda=_ld(x), B=wq.data_ptr(), ldb=K, D=y.data_ptr(), ldd=ncat,
                     B2=g.down_w16.data_ptr(), ldb2=K, D2=t.data_ptr(), ldd2=g.rp,
                     lr=dict(mode=2, rp=g.rp_each, b=g.up_t16.data_ptr(), ldb=g.rk, scale=scale, drop_p=drop_p, drop_seed=seeds[0],
-                            group_cols=g.npad_each, group_seeds=seeds[1:]))
+                            group_cols=g.npad_each, group_seeds=seeds[1:], plane=nv.ptr(plane)))
+        ctx.plane = plane
         ctx.g, ctx.scale, ctx.drop = g, scale, (drop_p, seeds)
         ctx.save_for_backward(x, t, *w_bases)
         return tuple(y[:, i * g.npad_each:(i + 1) * g.npad_each] for i in range(n))
@@ -1206,11 +1268,26 @@ class _LoraGroupDrop(torch.autograd.Function):
         cin_p, ncat = g.cin_p, g.npad
         rpe, npe = g.rp_each, g.npad_each
         dt = torch.empty(M, g.rp, dtype=BF16, device=x.device)          # dt_i = (mask_i dy_i / (1-p)) U_i, side by side
-        sd = (C.c_ulonglong * 3)(*(list(seeds) + [0] * (3 - n)))
-        nv.call("t2v_lora_drop_dt_group", dy_ptr, lddy, g.up_w16.data_ptr(), _ld(g.up_w16), rpe * _ld(g.up_w16) + npe, dt.data_ptr(), g.rp,
-                M, npe, rpe, n, drop_p, sd, nv.stream())
         dx = None
-        if need_dx:
+        kw3 = None
+        if need_dx and g.rp <= 64 and _dt_fuse_pays(M, cin_p, ncat, g.rp, n):
+            # round 6 (lr_mode 3): dt_cat is formed BY the backward-data launch (rank fragments on masked A fragments; the members
+            # partition K, each with its own seed and mask width) — no t2v_lora_drop_dt_group launch
+            wb = _group_weight(w_bases, "bwd")
+            dx = torch.empty(M, cin_p, dtype=BF16, device=x.device)
+            kw3 = dict(M=M, N=cin_p, K=ncat, A=dy_ptr, lda=lddy, B=wb.data_ptr(), ldb=ncat, D=dx.data_ptr(), ldd=cin_p,
+                       B2=g.up_w16.data_ptr(), ldb2=_ld(g.up_w16), D2=dt.data_ptr(), ldd2=g.rp,
+                       lr=dict(mode=3, rp=g.rp, b=g.down_t16.data_ptr(), ldb=_ld(g.down_t16), drop_p=drop_p, drop_seed=seeds[0],
+                               group_cols=npe if n > 1 else 0, group_seeds=seeds[1:], plane=nv.ptr(ctx.plane)))
+            if not _lr_ok(kw3):
+                kw3, dx = None, None
+        if kw3 is not None:
+            launch_gemm(**kw3)
+        else:
+            sd = (C.c_ulonglong * 3)(*(list(seeds) + [0] * (3 - n)))
+            nv.call("t2v_lora_drop_dt_group", dy_ptr, lddy, g.up_w16.data_ptr(), _ld(g.up_w16), rpe * _ld(g.up_w16) + npe, dt.data_ptr(), g.rp,
+                    M, npe, rpe, n, drop_p, sd, nv.stream())
+        if need_dx and kw3 is None:
             wb = _group_weight(w_bases, "bwd")
             dx = torch.empty(M, cin_p, dtype=BF16, device=x.device)
             launch_gemm(M=M, N=cin_p, K=ncat, A=dy_ptr, lda=lddy, B=wb.data_ptr(), ldb=ncat, D=dx.data_ptr(), ldd=cin_p,

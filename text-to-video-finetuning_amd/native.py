@@ -75,6 +75,7 @@ class Gemm(C.Structure):
         ("lr_scale", c_float), ("lr_drop_p", c_float), ("lr_drop_seed", c_ull),
         ("lr_group_cols", c_int), ("lr_group_seed", c_ull * 2),
         ("cs_drop_p", c_float), ("cs_drop_seed", c_ull),
+        ("lr_plane", c_void_p),
     ]
 
 
@@ -101,7 +102,7 @@ class Attn(C.Structure):
     ]
 
 
-ABI_VERSION = 7          # include/t2v_abi.h T2V_ABI_VERSION
+ABI_VERSION = 8          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
