@@ -27,7 +27,7 @@ typedef void* t2v_stream_t; /* hipStream_t */
 #define T2V_OK 0
 #define T2V_EINVAL (-1)
 #define T2V_ELAUNCH (-2)
-#define T2V_ABI_VERSION 8   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
+#define T2V_ABI_VERSION 9   /* bumped whenever a struct layout or a signature changes (native.py checks it) */
 
 int t2v_abi_version(void);
 const char* t2v_last_error(void);
@@ -285,6 +285,26 @@ typedef struct {
 } T2VAttn;
 int t2v_attn_fwd(const T2VAttn* p, t2v_stream_t stream);
 int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream);
+
+/* ---- the temporal self-attention unit of TransformerTemporalModel as ONE forward-only launch (ABI v9, csrc/temporal_fused.hip):
+ *   out = x + softmax_F((LN(x) Wq^T)(LN(x) Wk^T)^T * scale)(LN(x) Wv^T) Wo^T + bo
+ * = `norm1 -> attn1 -> + residual` / `norm2 -> attn2 -> + residual` of the BasicTransformerBlock inside every temp_attention and
+ * transformer_in (reference: models/unet_3d_blocks.py:331-340,491-500,726-735, models/unet_3d_condition.py:147-152,407-411; the
+ * leaf arithmetic is diffusers' BasicTransformerBlock / Attention with double_self_attention).  x / out: bf16 token matrices whose
+ * rows are ordered (batch b, frame f, pixel): row = (b F + f) HW + pixel; a sequence is the F rows of one pixel.  wqkv: bf16
+ * [3C, C] = the rows of to_q, to_k, to_v (nn.Linear layout, K contiguous); wo: bf16 [C, C]; bo, gamma, beta: fp32 [C] (bo may be
+ * NULL).  C = heads * 64.  Nothing is kept for a backward: the no-grad forward (sampling, train.py:908-958) only.
+ * t2v_temporal_fused_ok: 1 if the library has a kernel for this width / clip length. */
+typedef struct {
+  const void* x; long long ldx;
+  void* out; long long ldo;
+  const void* wqkv; const void* wo;
+  const float* bo; const float* gamma; const float* beta;
+  float eps, scale;
+  int B, F, HW, C;
+} T2VTemporalFused;
+int t2v_temporal_fused_fwd(const T2VTemporalFused* p, t2v_stream_t stream);
+int t2v_temporal_fused_ok(int C, int F);
 
 /* ---- row softmax (VAE mid-block single-head attention, d=512: scores are materialised per frame through the
  * batched GEMM).  In place allowed.  y[r,:] = softmax(x[r,:cols]) ---- */

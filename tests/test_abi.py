@@ -35,7 +35,7 @@ def test_ctypes_structs_mirror_header_sizes():
     prog = r'''
 #include <stdio.h>
 #include "t2v_abi.h"
-int main(){ printf("%zu %zu %zu %zu %zu\n", sizeof(T2VConvGeom), sizeof(T2VGemm), sizeof(T2VSmallConv), sizeof(T2VAttnOperand), sizeof(T2VAttn)); printf("%zu %zu %zu\n", sizeof(T2VLoraWgrad), sizeof(T2VLoraMergeJob), sizeof(T2VLoraPrepJob)); return 0; }
+int main(){ printf("%zu %zu %zu %zu %zu\n", sizeof(T2VConvGeom), sizeof(T2VGemm), sizeof(T2VSmallConv), sizeof(T2VAttnOperand), sizeof(T2VAttn)); printf("%zu %zu %zu %zu\n", sizeof(T2VLoraWgrad), sizeof(T2VLoraMergeJob), sizeof(T2VLoraPrepJob), sizeof(T2VTemporalFused)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(prog)
@@ -43,7 +43,7 @@ int main(){ printf("%zu %zu %zu %zu %zu\n", sizeof(T2VConvGeom), sizeof(T2VGemm)
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "p")]).split()))
     assert sizes == [ctypes.sizeof(nv.ConvGeom), ctypes.sizeof(nv.Gemm), ctypes.sizeof(nv.SmallConv),
                      ctypes.sizeof(nv.AttnOperand), ctypes.sizeof(nv.Attn), ctypes.sizeof(nv.LoraWgrad), ctypes.sizeof(nv.LoraMergeJob),
-                     ctypes.sizeof(nv.LoraPrepJob)]
+                     ctypes.sizeof(nv.LoraPrepJob), ctypes.sizeof(nv.TemporalFused)]
 
 
 def test_native_calls_fail_loudly_without_gpu_tensors():

@@ -94,7 +94,7 @@ def test_toy_optimizer_update_matches_oracle(toy):
 # ---- the reference's DEFAULT train mode: LoRA dropout 0.1 (utils/lora.py:35,89) + TemporalConvLayer dropout 0.1
 # (models/unet_3d_blocks.py:312; `eval_train` is opt-in, train.py:779-781).  The native masks are counter-based (csrc/common.h);
 # oracle/dropout.py restates seed, epoch and element index of every site, so the ORACLE runs the very same masks.
-def _dropout_pair(scale, r=4):
+def _dropout_pair(scale, r=4, frames=4):
     from oracle import dropout as odrop
     from t2v_amd.models import leaves
     from t2v_amd.training import DenoiseTrainer
@@ -108,7 +108,7 @@ def _dropout_pair(scale, r=4):
     params = [p for p in dunet.parameters() if p.requires_grad]
     trainer = DenoiseTrainer(dunet, dvae, params, lr=1e-3)
     # first _fwd_bwd of a fresh trainer: device epoch = (rank << 32) + 2, host step 0
-    ctx = odrop.install_protocol(ounet, base, step=0, epoch=2, batch=1, frames=4, passes=2)
+    ctx = odrop.install_protocol(ounet, base, step=0, epoch=2, batch=1, frames=frames, passes=2)
     return ounet, ovae, dunet, dvae, trainer, ctx
 
 
@@ -150,6 +150,51 @@ def test_toy_default_train_mode_with_dropout_matches_oracle(scale):
     #  dropped branches move by ~sqrt(p / (1 - p)) whatever the draw)
     assert abs(l_off - l_ref) / abs(l_ref) > 3 * max(rel, 1e-4)
     assert off["rel"] > cmp["rel"]
+
+
+# BASELINE.json configs[3..4] in the mode the reference trains them in (round 6): LoRA rank 16 on the C4 grid
+# (576x320 pixels -> 40x72 latents) and rank 32 on the bucketed 1024x384 -> 48x128 grid, with the wrappers' and the
+# TemporalConvLayers' dropout ACTIVE — the epilogue rank terms, the grouped projections with 16 / 32 ranks per member, the keep-bit
+# planes + lr_mode 3 where they apply, the masked dt / dU kernels — at reduced width and clip length (8 / 4 frames) against the CPU
+# oracle running the restated masks.  The oracle's side is a committed fixture (tests/golden/make_grid_fixture.py: loss + EVERY
+# factor gradient; restating every mask element on the host takes 2.5 - 3.5 minutes per grid, measured live in round 6:
+# profiles/r06_call5_pytest.log — loss 9e-5 / 6e-5, gradients 0.034 / 0.046, worst cosine 0.976 / 0.954).
+@pytest.mark.parametrize("frames,h,w,r", [(8, 40, 72, 16), (4, 48, 128, 32)])
+def test_default_train_mode_lora_on_the_shipped_grids(frames, h, w, r):
+    import importlib.util
+    import os
+    import parity_utils as pu
+    from t2v_amd.models import leaves
+    from t2v_amd.training import DenoiseTrainer
+    spec = importlib.util.spec_from_file_location("make_grid_fixture", os.path.join(pu.GOLDEN, "make_grid_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    path = mk.grid_path(frames, h, w, r)
+    assert os.path.exists(path), path
+    fx = torch.load(path, weights_only=False)
+    ounet, ovae, _ = pu.build_oracle(False, r, mk.SCALE)
+    assert abs(pu.weight_checksum(ounet, ovae) - fx["checksum"]) <= 1e-6 * abs(fx["checksum"]), "fixture made for other weights"
+    dunet, dvae = pu.build_native(ounet, ovae, False, r)
+    del ounet, ovae
+    pu.enable_reference_dropout(dunet)
+    leaves.set_dropout_seed(pu.DROPOUT_BASE_SEED)
+    trainer = DenoiseTrainer(dunet, dvae, [p for p in dunet.parameters() if p.requires_grad], lr=1e-3)
+    l_dut, g_dut = pu.native_loss_and_grads(trainer, dunet, mk.grid_batch(frames, h, w, r))     # first step: epoch 2, host step 0
+    l_ref, g_ref = fx["loss"], {n: g.float() for n, g in fx["grads"].items()}
+    rel = abs(l_dut - l_ref) / abs(l_ref)
+    cmp = pu.compare_grads(g_ref, g_dut)
+    big = pu.compare_grads(g_ref, g_dut, share=1e-2)
+    print(f"default mode, grid {frames}x{h}x{w}, r={r}: loss oracle {l_ref:.6f} native {l_dut:.6f} rel {rel:.2e}; grads rel {cmp['rel']:.3f} "
+          f"cos {cmp['cos']:.4f} worst tensor rel {cmp['worst_rel']:.3f} cos {cmp['worst_cos']:.3f} over {cmp['tensors']}; among the "
+          f"{big['tensors']} tensors >= 1 % of the norm: worst cos {big['worst_cos']:.3f}")
+    _record(test="default_mode_shipped_grid", frames=frames, h=h, w=w, r=r, loss_rel=rel, grad_rel=cmp["rel"], grad_cos=cmp["cos"],
+            worst_cos=cmp["worst_cos"], worst_cos_big=big["worst_cos"])
+    # loss: north_star's 1e-3 (these grids have 45 - 96x the latent positions of the 4-frame 8x8 toy clip); gradients: the toy
+    # default-mode gates, tightened to what these grids measure (0.034 / 0.046 whole gradient, worst cosine 0.95 - 0.98)
+    assert rel < 1e-3
+    assert cmp["rel"] < 0.12 and cmp["cos"] > 0.99
+    assert big["worst_cos"] > 0.9 and cmp["worst_cos"] > 0.8
+    assert all(float(g.abs().max()) > 0 for n, g in g_dut.items()), "every factor receives a gradient"
 
 
 def test_toy_rank_beyond_the_merge_window_trains_and_matches_oracle():

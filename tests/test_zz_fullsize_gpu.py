@@ -58,6 +58,7 @@ def _fixture_tools():
 # 0.137, every tensor BELOW its own bf16-recipe floor (0.13 - 0.17); amplitude 0.2: 0.273 on the to_q tensor above (floor 0.294), worst
 # ratio to the floor 1.36 (down_blocks.2.attentions.0 ... to_v: 0.235 vs 0.173); fixtures without a floor arm: C1 default mode 0.127,
 # C2 0.146, C2 default mode 0.128, C3 0.153 / 0.152.
+FULL_SUITE = os.environ.get("T2V_TEST_FULL", "0") == "1"     # every amplitude / fixture (the round-5 suite: 685 s on one MI355X)
 MIN_TENSOR_FLOOR = 0.10
 TRUE_TENSOR_BAR = 0.20      # round 6: 0.25 -> 0.20 (measured 0.127 - 0.153 on the five fixtures without a floor arm)
 
@@ -164,10 +165,16 @@ def test_full_c1_loss_and_lora_gradients():
     """ModelScope-1.7B shapes, config C1 (8 frames @128x128, LoRA r=4): LoRA `up` amplitudes 0 (the reference's init,
     utils/lora.py:55), 0.02 and 0.2 of N(0, 1/r); the N(0,1/r) point itself is reported, not asserted: there the network
     leaves its trained regime (loss ~32) and the reference's OWN bf16 recipe has a gradient error of 5.75 (floor file)."""
-    rows = _full_case("c1", [0.0, 0.02, 0.2, 1.0])
-    for row, bad in rows[:3]:
-        _assert_case(row, bad)
-    assert rows[3][0]["loss_rel"] < 5e-2
+    # (round 6: the amplitudes 0.02 and 1.0 run only with T2V_TEST_FULL=1 — the suite must fit the driver's time limit with the
+    #  new default-mode grid tests; 0 is the reference's init, 0.2 the hardest asserted point, 0.02 is covered at C2 and in both
+    #  default-mode fixtures)
+    scales = [0.0, 0.02, 0.2, 1.0] if FULL_SUITE else [0.0, 0.2]
+    rows = _full_case("c1", scales)
+    for (row, bad), sc in zip(rows, scales):
+        if sc < 1.0:
+            _assert_case(row, bad)
+        else:
+            assert row["loss_rel"] < 5e-2
 
 
 def test_full_c2_loss_and_lora_gradients():
@@ -176,7 +183,8 @@ def test_full_c2_loss_and_lora_gradients():
     _assert_case(row, bad)
 
 
-@pytest.mark.parametrize("config", ["c3", "c3full"])
+@pytest.mark.parametrize("config", [pytest.param("c3", marks=pytest.mark.skipif(not FULL_SUITE, reason="C3 on the C1 clip: T2V_TEST_FULL=1 "
+                                                                                "(c3full, C3's own clip, always runs)")), "c3full"])
 def test_c3_full_finetune_gradients_match_the_oracle_fixture(config):
     """Config C3 (BASELINE.json configs[2], train.py:172-236: every UNet parameter trainable, no LoRA) at FULL model size: loss
     and the gradient of all 1.41 B parameters — complete +-1 sketch, per-tensor norms, exact samples — against the committed

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libt2v_hip.so")
-SOURCES = ["gemm.hip", "gemm_w8.hip", "norm.hip", "attn.hip", "elementwise.hip", "lora_wgrad.hip", "lora_merge.hip"]
+SOURCES = ["gemm.hip", "gemm_w8.hip", "norm.hip", "attn.hip", "elementwise.hip", "lora_wgrad.hip", "lora_merge.hip", "temporal_fused.hip"]
 # translation units: (source, object, extra flags).  gemm_w8.hip is compiled three times with -DW8_PART=0/1/2 (plain kernels + entry
 # points / LR = 1 kernels / LR = 2 kernels): its ~60 kernel instantiations took 3 minutes in one hipcc process
 UNITS = [(s, s.replace(".hip", ".o"), []) for s in SOURCES if s != "gemm_w8.hip"] + \

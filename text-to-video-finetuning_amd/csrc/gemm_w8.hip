@@ -1137,13 +1137,42 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
                 t[x].x += ld[x].x; t[x].y += ld[x].y; t[x].z += ld[x].z; t[x].w += ld[x].w;
               }
             };
-            for (int z = 0; z < bz; ++z) add_slab(z);
+            // two slabs per round trip (round 6: the reducer's slab reads are dependent round trips to another XCD's L2 / the
+            // Infinity Cache, ~1.5 us each; six to eight splits spent 10 us of a 27 us launch here) — same summation order
+            auto add_slabs2 = [&](int z) {
+              float4 la[GRP * 4], lb[GRP * 4];
+#pragma unroll
+              for (int x = 0; x < GRP * 4; ++x) la[x] = sl[(long long)z * ZS + ((g0 * 4) + x) * 64];
+#pragma unroll
+              for (int x = 0; x < GRP * 4; ++x) lb[x] = sl[(long long)(z + 1) * ZS + ((g0 * 4) + x) * 64];
+#pragma unroll
+              for (int x = 0; x < GRP * 4; ++x) {
+                t[x].x += la[x].x; t[x].y += la[x].y; t[x].z += la[x].z; t[x].w += la[x].w;
+              }
+#pragma unroll
+              for (int x = 0; x < GRP * 4; ++x) {
+                t[x].x += lb[x].x; t[x].y += lb[x].y; t[x].z += lb[x].z; t[x].w += lb[x].w;
+              }
+            };
+            constexpr bool PAIRS = KG == 2;          // (the K-group tiles hold 3 - 4 fragments per wave: registers to spare; the
+                                                     //  128x384 / 256x256 kernels spilled with a second slab in flight)
+            {
+              int z = 0;
+              if constexpr (PAIRS)
+                for (; z + 1 < bz; z += 2) add_slabs2(z);
+              for (; z < bz; ++z) add_slab(z);
+            }
 #pragma unroll
             for (int x = 0; x < GRP * 4; ++x) {
               const float4 own = quad(acc[(g0 + x / 4) / FN][(g0 + x / 4) % FN], x % 4);
               t[x].x += own.x; t[x].y += own.y; t[x].z += own.z; t[x].w += own.w;
             }
-            for (int z = bz + 1; z < splits; ++z) add_slab(z);
+            {
+              int z = bz + 1;
+              if constexpr (PAIRS)
+                for (; z + 1 < splits; z += 2) add_slabs2(z);
+              for (; z < splits; ++z) add_slab(z);
+            }
 #pragma unroll
             for (int x = 0; x < GRP * 4; ++x) {
               f32x16& d = acc[(g0 + x / 4) / FN][(g0 + x / 4) % FN];

@@ -1600,6 +1600,40 @@ def attention(q, k, v, heads, qlay, klay, scale=0.125, causal=False):
     return _Attention.apply(q, k, v, int(heads), qlay, klay, float(scale), bool(causal))
 
 
+# --------------------------------------------------------------------------- fused temporal unit (forward only)
+_temporal_fused = os.environ.get("T2V_TEMPORAL_FUSED", "1") != "0"
+
+
+def temporal_fused_ok(C_, frames):
+    """The library has a one-launch kernel for `LN -> q,k,v -> FxF softmax -> PV -> out-proj -> + residual` at this width / clip
+    length (csrc/temporal_fused.hip) and the switch T2V_TEMPORAL_FUSED is on."""
+    return _temporal_fused and bool(nv.lib().t2v_temporal_fused_ok(int(C_), int(frames)))
+
+
+def temporal_attention_fused(x, gamma, beta, eps, wqkv, wo, bo, batch, frames, hw, scale=0.125):
+    """out = x + softmax_F((LN(x) Wq^T)(LN(x) Wk^T)^T scale)(LN(x) Wv^T) Wo^T + bo in ONE launch, nothing kept for a backward
+    (include/t2v_abi.h `t2v_temporal_fused_fwd`).  x: [batch*frames*hw, C] bf16 token matrix, rows (b, f, pixel); wqkv: bf16 [3C, C]
+    (rows of to_q, to_k, to_v), wo: bf16 [C, C]."""
+    if torch.is_grad_enabled() and (x.requires_grad or wqkv.requires_grad or wo.requires_grad):
+        raise RuntimeError("t2v_amd: temporal_attention_fused is forward-only; call it under torch.no_grad()")
+    x = _mat(x, "x")
+    Cc = wo.shape[0]
+    if x.shape[0] != batch * frames * hw or x.shape[1] < Cc or tuple(wqkv.shape) != (3 * Cc, Cc) or tuple(wo.shape) != (Cc, Cc):
+        raise RuntimeError("t2v_amd: temporal_attention_fused: operand shapes do not match")
+    if wqkv.dtype != BF16 or wo.dtype != BF16 or not wqkv.is_contiguous() or not wo.is_contiguous():
+        raise RuntimeError("t2v_amd: temporal_attention_fused wants contiguous bf16 weights")
+    out = torch.empty(x.shape[0], Cc, dtype=BF16, device=x.device)
+    d = nv.TemporalFused()
+    d.x, d.ldx, d.out, d.ldo = x.data_ptr(), _ld(x), out.data_ptr(), Cc
+    d.wqkv, d.wo = wqkv.data_ptr(), wo.data_ptr()
+    g32, b32, bo32 = _f32(gamma), _f32(beta), _f32(bo)
+    d.bo, d.gamma, d.beta = nv.ptr(bo32), g32.data_ptr(), b32.data_ptr()
+    d.eps, d.scale = float(eps), float(scale)
+    d.B, d.F, d.HW, d.C = int(batch), int(frames), int(hw), int(Cc)
+    nv.call("t2v_temporal_fused_fwd", C.byref(d), nv.stream())
+    return out
+
+
 # --------------------------------------------------------------------------- GEGLU / SiLU
 class _Geglu(torch.autograd.Function):
     @staticmethod

@@ -352,6 +352,54 @@ class Attention(nn.Module):
         return run_layer(self.to_out[0], o, residual=residual)
 
 
+def _effective_weight(mod):
+    """(tag, make) of the weight a Linear leaf — or a cloneofsimo LoRA wrapper around one, dropout inactive, no selector — applies
+    in a forward: W, or W + scale * up @ down (utils/lora.py:57-62 with the Dropout in eval mode).  None: not expressible."""
+    if isinstance(mod, nn.Linear) and not hasattr(mod, "lora_A"):
+        w = mod.weight
+        return ("lin", w.data_ptr(), w._version), (lambda: F.prepared_weight(w, "fwd")), mod.bias
+    base = getattr(mod, "linear", None)
+    if base is None or not (hasattr(mod, "lora_down") and hasattr(mod, "lora_up")) or _drop_p(getattr(mod, "dropout", None)) > 0.0:
+        return None
+    sel = getattr(mod, "selector", None)
+    if sel is not None and not isinstance(sel, nn.Identity):
+        return None
+    w, u, d, sc = base.weight, mod.lora_up.weight, mod.lora_down.weight, float(mod.scale)
+    if w.shape[0] % 8 or w.shape[1] % 8:
+        return None
+    tag = ("lora", w.data_ptr(), w._version, u.data_ptr(), u._version, d.data_ptr(), d._version, sc)
+
+    def make():
+        with torch.no_grad():
+            return (w.detach().float() + sc * _low_rank_product(u.detach(), d.detach())).to(BF16).contiguous()
+    return tag, make, base.bias
+
+
+def _temporal_unit_fused(norm, attn, t, qlay):
+    """`t + attn(norm(t))` of a temporal BasicTransformerBlock as one launch (functional.temporal_attention_fused), or None when the
+    one-launch form does not apply: rows not in the (batch, frame, pixel) order of TransformerTemporalModel, a width / clip length
+    the library has no kernel for, projection biases, or a LoRA flavour whose forward is not `W + s up down`."""
+    hw, frames = qlay.bdiv, qlay.S
+    if not (qlay.ss == hw and qlay.lo == 1 and qlay.hi == frames * hw and qlay.nbatch % hw == 0):
+        return None
+    width = attn.heads * 64
+    if t.shape[1] != width or not F.temporal_fused_ok(width, frames):
+        return None
+    parts = [_effective_weight(m) for m in (attn.to_q, attn.to_k, attn.to_v, attn.to_out[0])]
+    if any(p is None for p in parts) or any(p[2] is not None for p in parts[:3]):
+        return None
+    if any(tuple(m.weight.shape if isinstance(m, nn.Linear) else m.linear.weight.shape) != (width, width)
+           for m in (attn.to_q, attn.to_k, attn.to_v, attn.to_out[0])):
+        return None
+    tag = tuple(p[0] for p in parts)
+    hit = attn.__dict__.get("_t2v_fused_w")
+    if hit is None or hit[0] != tag or hit[1].device != t.device:
+        hit = (tag, torch.cat([p[1]() for p in parts[:3]], dim=0).contiguous(), parts[3][1]())
+        attn.__dict__["_t2v_fused_w"] = hit
+    return F.temporal_attention_fused(t, norm.weight, norm.bias, norm.eps, hit[1], hit[2], parts[3][2], qlay.nbatch // hw, frames, hw,
+                                      attn.scale)
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
@@ -384,6 +432,17 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, t, qlay, ctx=None, klay=None):
+        if ctx is None and not torch.is_grad_enabled():
+            # forward-only temporal block (sampling, validation): `norm -> attn -> + residual` as ONE launch each
+            # (csrc/temporal_fused.hip) where the library has the kernel; the feed-forward keeps its launches
+            for norm, attn in ((self.norm1, self.attn1), (self.norm2, self.attn2)):
+                out = _temporal_unit_fused(norm, attn, t, qlay)
+                if out is None:
+                    n, r = F.layer_norm_res(t, norm.weight, norm.bias, norm.eps)
+                    out = attn(n, qlay, residual=r)
+                t = out
+            n, r = F.layer_norm_res(t, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            return self.ff(n, residual=r)
         # (normalised, pass-through) pairs: the residual's gradient is summed inside each LayerNorm's backward kernel
         n, r = F.layer_norm_res(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         t = self.attn1(n, qlay, residual=r)

@@ -102,7 +102,15 @@ class Attn(C.Structure):
     ]
 
 
-ABI_VERSION = 8          # include/t2v_abi.h T2V_ABI_VERSION
+class TemporalFused(C.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_ll), ("out", c_void_p), ("ldo", c_ll), ("wqkv", c_void_p), ("wo", c_void_p),
+        ("bo", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("scale", c_float),
+        ("B", c_int), ("F", c_int), ("HW", c_int), ("C", c_int),
+    ]
+
+
+ABI_VERSION = 9          # include/t2v_abi.h T2V_ABI_VERSION
 A_DENSE, A_CONV = 0, 1
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
@@ -112,6 +120,8 @@ SYMBOLS = {
     "t2v_abi_version": ([], c_int),
     "t2v_last_error": ([], C.c_char_p),
     "t2v_gemm": ([C.POINTER(Gemm), c_void_p], c_int),
+    "t2v_temporal_fused_fwd": ([C.POINTER(TemporalFused), c_void_p], c_int),
+    "t2v_temporal_fused_ok": ([c_int, c_int], c_int),
     "t2v_gemm_lr_ok": ([C.POINTER(Gemm)], c_int),
     "t2v_gemm_colsum_rows": ([C.POINTER(Gemm)], c_int),
     "t2v_gn_finish": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
