@@ -417,6 +417,95 @@ def gemm_roofline(trainer, batch):
     return out
 
 
+def temporal_fused_forward(unet, frames, H, W, dev):
+    """SURVEY 8(d)'s fused temporal unit as ONE kernel (csrc/temporal_fused.hip), measured where the product runs it: a no-grad,
+    CFG-doubled UNet forward in eval mode = one UNet call of a sampling step (train.py:908-958, inference.py:153-267) on the
+    benchmark's clip shape, LoRA wrappers folded (W + s up down).  Every `t2v_temporal_fused_fwd` launch is timed by its own
+    begin / end timestamps (hipExtLaunchKernelGGL through the library's measurement hook); flops = 8 C^2 T + 4 T F C per unit.
+    Beside it: the wall time of that forward with the one-launch unit and with the separate launches (T2V_TEMPORAL_FUSED=0 path)."""
+    import t2v_amd.functional as F
+    nv = F.nv
+    lib = nv.lib()
+    kev = _KernelEvents()
+    recs = []
+    orig_call = nv.call
+
+    def timed_call(name, *a):
+        if name != "t2v_temporal_fused_fwd":
+            return orig_call(name, *a)
+        d = a[0]._obj
+        inner = kev.pair()
+        if inner is not None:
+            lib.t2v_launch_timing_events(inner[0], inner[1])
+        r = orig_call(name, *a)
+        if inner is not None and lib.t2v_launch_timing_consumed():
+            recs.append((int(d.C), int(d.B) * int(d.F) * int(d.HW), int(d.F), inner))
+        return r
+
+    was_training = unet.training
+    unet.eval()
+    g = torch.Generator(device="cpu").manual_seed(99)
+    lat = torch.randn(2, 4, frames, H // 8, W // 8, generator=g).to(dev)
+    ts = torch.tensor([500, 500], device=dev)
+    ehs = torch.randn(2, 77, 1024, generator=g).to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            return unet(lat, ts, encoder_hidden_states=ehs).sample
+
+    def wall(n=5):
+        fwd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fwd()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    try:
+        out_f = fwd()
+        ms_fused = wall()
+        nv.call = timed_call
+        fwd()
+        torch.cuda.synchronize()
+        nv.call = orig_call
+        was = F._temporal_fused
+        F._temporal_fused = False
+        try:
+            out_s = fwd()
+            ms_sep = wall()
+        finally:
+            F._temporal_fused = was
+        rel = float((out_f.float() - out_s.float()).norm() / out_s.float().norm())
+    finally:
+        nv.call = orig_call
+        unet.train(was_training)
+    if not recs:
+        kev.close()
+        return None
+    by = {}
+    for Cc, T, Fr, inner in recs:
+        a = by.setdefault(Cc, [0, 0.0, 0.0, T])
+        a[0] += 1
+        a[1] += kev.ms(inner) or 0.0
+        a[2] += 8.0 * Cc * Cc * T + 4.0 * T * Fr * Cc
+    kev.close()
+    fl, ms = sum(a[2] for a in by.values()), sum(a[1] for a in by.values())
+    return {"what": "SURVEY 8(d) fused temporal unit LN -> QKV -> FxF softmax -> PV -> out-proj -> +residual as ONE kernel "
+                    "(temporal_fused_fwd_kernel<C,NBO>), forward-only: the launches of one no-grad CFG-doubled UNet forward in eval mode "
+                    "(a sampling step's UNet call) on this config's clip; kernel begin/end timestamps",
+            "units_one_launch": len(recs), "units_total": 34, "ms": round(ms, 3), "GFLOP": round(fl / 1e9, 1),
+            "TFLOP/s": round(fl / ms / 1e9, 1), "frac_mfma_peak": round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "per_width": {str(Cc): {"units": a[0], "rows": a[3], "us_per_unit": round(a[1] / a[0] * 1e3, 1),
+                                    "TFLOP/s": round(a[2] / a[1] / 1e9, 1), "frac_mfma_peak": round(a[2] / a[1] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
+                          for Cc, a in sorted(by.items())},
+            "policy": "widths <= 512 take the one-launch kernel (functional.temporal_fused_ok); the C = 1280 levels have 4 - 16 row tiles "
+                      "per launch and stay on separate launches, C = 640 loses to them (registers)",
+            "sampling_unet_forward_ms": {"one_launch_units": round(ms_fused, 2), "separate_launches": round(ms_sep, 2),
+                                         "eager, host-timed, batch 2 (CFG pair)": True},
+            "one_launch_vs_separate_relerr": round(rel, 6)}
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel family in the step AS IT RUNS (every tile the shipped table selects),
     from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r05_pmc_step.json, else round 4's: rocprofv3 --pmc
@@ -724,6 +813,12 @@ def main():
                                "note": "at config c3 (full finetune) this family carries every full weight gradient dW = x^T dy"},
                     graph_replay_rocprof=rocprof_family_time(rr["flops"]) if args.config == "c2" else None,
                     north_star_kernels=both["north_star"])
+        try:
+            tfu = temporal_fused_forward(unet, frames, H, W, dev)
+            if tfu is not None:
+                roof["north_star_kernels"]["temporal_fused_forward_unit"] = tfu
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] fused temporal unit measurement failed: {type(e).__name__}: {e}", file=sys.stderr)
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_steps, dev, c2_once=not args.no_cpu_c2)

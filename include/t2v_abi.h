@@ -292,8 +292,10 @@ int t2v_attn_bwd(const T2VAttn* p, t2v_stream_t stream);
  * transformer_in (reference: models/unet_3d_blocks.py:331-340,491-500,726-735, models/unet_3d_condition.py:147-152,407-411; the
  * leaf arithmetic is diffusers' BasicTransformerBlock / Attention with double_self_attention).  x / out: bf16 token matrices whose
  * rows are ordered (batch b, frame f, pixel): row = (b F + f) HW + pixel; a sequence is the F rows of one pixel.  wqkv: bf16
- * [3C, C] = the rows of to_q, to_k, to_v (nn.Linear layout, K contiguous); wo: bf16 [C, C]; bo, gamma, beta: fp32 [C] (bo may be
- * NULL).  C = heads * 64.  Nothing is kept for a backward: the no-grad forward (sampling, train.py:908-958) only.
+ * [3C, C] = the rows of to_q, to_k, to_v (nn.Linear layout, K contiguous); wo: bf16 [C, C] = to_out.0's weight with its INPUT
+ * index permuted inside every group of 16: stored position 16 g + 8 a + 4 b + c holds input 16 g + 8 b + 4 a + c (a, b in {0, 1},
+ * c in 0..3) — the order in which a lane of the O^T accumulators holds head dims, so that a fragment is one 16-byte LDS read;
+ * bo, gamma, beta: fp32 [C] (bo may be NULL).  C = heads * 64.  Nothing is kept for a backward: the no-grad forward (sampling, train.py:908-958) only.
  * t2v_temporal_fused_ok: 1 if the library has a kernel for this width / clip length. */
 typedef struct {
   const void* x; long long ldx;
@@ -302,6 +304,8 @@ typedef struct {
   const float* bo; const float* gamma; const float* beta;
   float eps, scale;
   int B, F, HW, C;
+  int ablate;      /* measurement only (scripts/temporal_fused_probe.py), 0 in every product call: bit 0 = no output pass (residual read,
+                    * stores), bit 1 = no LayerNorm input pass, bit 2 = no weight traffic (LDS-DMA), bit 3 = no MFMA k-loops */
 } T2VTemporalFused;
 int t2v_temporal_fused_fwd(const T2VTemporalFused* p, t2v_stream_t stream);
 int t2v_temporal_fused_ok(int C, int F);

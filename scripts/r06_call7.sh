@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -x -k "temporal_unit_fused or temporal_block_no_grad" > gpurun_out/r06_call7_pytest.log 2>&1
+echo "pytest rc=$?"; tail -30 gpurun_out/r06_call7_pytest.log | cut -c1-300
+timeout 300 python scripts/temporal_fused_probe.py c2 > gpurun_out/r06_temporal_fused_probe_v1.txt 2>&1; cat gpurun_out/r06_temporal_fused_probe_v1.txt | tail -8
+timeout 300 python scripts/temporal_fused_probe.py c4 >> gpurun_out/r06_temporal_fused_probe_v1.txt 2>&1; cat gpurun_out/r06_temporal_fused_probe_v1.txt | tail -7

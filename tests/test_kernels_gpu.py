@@ -196,6 +196,70 @@ def test_attention_temporal_strided(B, Fr, HW, heads):
     assert relerr(vd.grad.view(B, Fr, HW, C), vr.grad) < 3e-2
 
 
+@pytest.mark.parametrize("B,Fr,HW,C", [(1, 16, 67, 320), (2, 24, 19, 640), (1, 8, 33, 512), (2, 5, 9, 64), (1, 4, 64, 128),
+                                       (1, 32, 7, 320), (1, 16, 1024, 640)])
+def test_temporal_unit_fused_forward(B, Fr, HW, C):
+    """`x + attn(LN(x))` of a temporal BasicTransformerBlock (models/unet_3d_blocks.py:331-340 -> diffusers BasicTransformerBlock
+    with double_self_attention) as ONE launch (csrc/temporal_fused.hip) against plain fp32 PyTorch on the same bf16-rounded
+    operands; ragged tails (pixel counts that do not fill a block), clip lengths 4 .. 32 (24 = the Zeroscope clip: 8 idle row slots
+    per block), every width the library has a kernel for."""
+    import t2v_amd.functional as F
+    assert F.temporal_fused_ok(C, Fr, policy=False)
+    g = torch.Generator().manual_seed(B * 1000 + Fr * 10 + HW + C)
+    heads = C // 64
+    x = _bf(torch.randn(B, Fr, HW, C, generator=g) * 1.5 + 0.3)
+    wq, wk, wv, wo = (_bf(torch.randn(C, C, generator=g) * C ** -0.5) for _ in range(4))
+    bo = torch.randn(C, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xr = x.float()
+    n = TF.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    tf = lambda t: t.permute(0, 2, 1, 3).reshape(B * HW, Fr, C)            # (b hw) f c
+    o = _sdpa_ref(tf(n @ wq.float().t()), tf(n @ wk.float().t()), tf(n @ wv.float().t()), heads)
+    ref = xr + (o.view(B, HW, Fr, C).permute(0, 2, 1, 3) @ wo.float().t() + bo)
+    out = F.temporal_attention_fused(x.reshape(-1, C).cuda(), gamma.cuda(), beta.cuda(), 1e-5, torch.cat([wq, wk, wv]).cuda(),
+                                     F.temporal_fused_prepare_wo(wo.cuda()), bo.cuda(), B, Fr, HW)
+    torch.cuda.synchronize()
+    assert out.shape == (B * Fr * HW, C) and bool(torch.isfinite(out.float()).all())
+    # the unit's own contribution (out - x) is what the kernel computes: bound it apart from the pass-through residual
+    assert relerr(out.float().cpu().view(B, Fr, HW, C) - xr, ref - xr) < TOL
+    assert relerr(out.view(B, Fr, HW, C), ref) < 1e-2
+
+
+def test_temporal_block_no_grad_forward_takes_the_fused_unit_and_matches_the_training_forward():
+    """A TransformerTemporalModel under torch.no_grad() (sampling: train.py:908-958) runs both attention units of its block through
+    the one-launch kernel — with plain Linear projections and with cloneofsimo LoRA wrappers (W + s up down folded for the call) —
+    and must agree with the SAME module's grad-enabled forward (separate LayerNorm / q,k,v / core / out-proj launches)."""
+    import t2v_amd.functional as F
+    from t2v_amd.models import leaves
+    from t2v_amd.utils.lora import inject_trainable_lora_extended
+    torch.manual_seed(5)
+    m = leaves.TransformerTemporalModel(num_attention_heads=5, attention_head_dim=64, in_channels=320, num_layers=1).cuda()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    B, Fr, H, W = 1, 16, 6, 5
+    x = leaves.Tok.from_nchw(torch.randn(B * Fr, 320, H, W).cuda())
+    calls = []
+    real = F.temporal_attention_fused
+    F.temporal_attention_fused = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for lora in (False, True):
+            if lora:
+                inject_trainable_lora_extended(m, target_replace_module={"TransformerTemporalModel"}, r=8)
+                for n_, p in m.named_parameters():
+                    if "lora_up" in n_:
+                        torch.nn.init.normal_(p, std=0.05)
+                m.cuda().eval()                                  # (the wrappers' Dropout(0.1) off: sampling runs in eval mode)
+            calls.clear()
+            with torch.no_grad():
+                y0 = m(x, num_frames=Fr).sample.m.float()
+            assert len(calls) == 2, "both attention units of the block take the fused launch"
+            y1 = m(x, num_frames=Fr).sample.m.float()           # grad mode: the training forward
+            assert len(calls) == 2
+            assert relerr(y0, y1) < 1e-2, (lora, relerr(y0, y1))
+    finally:
+        F.temporal_attention_fused = real
+
+
 def test_attention_cross_shared_kv():
     """Text K/V shared by all frames of a video (encoder_hidden_states.repeat_interleave, unet_3d_condition.py:401)."""
     import t2v_amd.functional as F

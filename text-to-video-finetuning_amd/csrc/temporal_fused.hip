@@ -20,7 +20,7 @@
 //   * O^T (lane = row slot, registers = head dims) is the A operand of the output projection; the permutation of its head dims
 //     is undone by reading the Wo fragment as two 8-byte halves instead of one 16-byte chunk.
 // Only WEIGHTS go through LDS: [192 x 64] chunks (q | k | v rows of one head, 64 input channels) and then [NBO*32 x 64] chunks of
-// Wo stream through a three-stage ring by LDS-DMA (buffer_load ... lds, 16 B per lane, lane-linear image with the XOR swizzle
+// Wo stream through a four-stage ring by LDS-DMA (buffer_load ... lds, 16 B per lane, lane-linear image with the XOR swizzle
 // of csrc/gemm.hip), counted s_waitcnt vmcnt + one s_barrier per chunk.  One workgroup per CU (up to ~460 registers per lane).
 //
 // Rooflines: MFMA-bound, 8 C^2 + 4 F C flops per row against 2.5 PFLOP/s; every workgroup reads all 4 C^2 weights once from
@@ -32,8 +32,10 @@ namespace {
 constexpr int TF_BK = 64;
 constexpr int TF_STAGE_ROWS = 192;
 constexpr int TF_STAGE = TF_STAGE_ROWS * TF_BK * 2;   // 24 KB
-constexpr int TF_NSTAGE = 3;
+constexpr int TF_NSTAGE = 4;
 constexpr int TF_NT = 256;
+constexpr int TF_STG_PITCH = 36;                      // floats per row of the per-wave output staging tile (32 columns + 16 bytes)
+constexpr int TF_SMEM = TF_NSTAGE * TF_STAGE + 4 * 32 * TF_STG_PITCH * 4;
 
 template <int N>
 __device__ __forceinline__ void tf_wait_vmcnt() {
@@ -44,6 +46,29 @@ __device__ __forceinline__ bf16x8 tf_pack8(const f32x16& a, int r0) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   const u32x4 q = {pack2bf(a[r0], a[r0 + 1]), pack2bf(a[r0 + 2], a[r0 + 3]), pack2bf(a[r0 + 4], a[r0 + 5]), pack2bf(a[r0 + 6], a[r0 + 7])};
   return __builtin_bit_cast(bf16x8, q);
+}
+
+// Fragment reads are hand-issued (ds_read_b128 through inline asm, explicit s_waitcnt lgkmcnt): the compiler's scheduler sinks
+// every LDS read to just in front of the MFMA that consumes it (read -> wait -> multiply, one at a time: measured 0.11 of peak),
+// and with one wave per SIMD nothing else hides that latency.  Here the reads of k-step i+1 are issued, then the MFMAs of k-step i.
+template <int OFF>
+__device__ __forceinline__ void tf_lds_read(bf16x8& w, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void tf_lds_read_n(bf16x8 (&w)[N], unsigned addr) {
+  tf_lds_read<0>(w[0], addr);
+  if constexpr (N > 1) tf_lds_read<4096>(w[1], addr);
+  if constexpr (N > 2) tf_lds_read<8192>(w[2], addr);
+  if constexpr (N > 3) tf_lds_read<12288>(w[3], addr);
+  if constexpr (N > 4) tf_lds_read<16384>(w[4], addr);
+  if constexpr (N > 5) tf_lds_read<20480>(w[5], addr);
+}
+template <int N>
+__device__ __forceinline__ void tf_lds_wait(bf16x8 (&w)[N]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(w[j]));      // the fragments are defined from here on
 }
 
 // C = heads * 64; NBO = 32-column tiles per output-projection chunk (C % (NBO * 32) == 0, NBO <= 6)
@@ -64,15 +89,18 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
 
   // ---- weight ring (all four waves issue; chunk g of the flat stream: g < NA -> head g / KC, k-chunk g % KC of [Wq; Wk; Wv],
   //      then output chunk (g - NA) / KC, k-chunk (g - NA) % KC of Wo)
-  const __amdgpu_buffer_rsrc_t srdQ = __builtin_amdgcn_make_buffer_rsrc((void*)p.wqkv, 0, 0x80000000u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void*)p.wo, 0, 0x80000000u, 0x00020000);
   const int kcs = (tid & 7) ^ ((tid >> 4) & 7);                       // source 16-byte chunk of this lane's LDS slot (swizzle)
   const unsigned vbase = ((unsigned)(tid >> 3) * (unsigned)C + (unsigned)kcs * 8u) * 2u;
+  const int abl = p.ablate;
   auto issue = [&](int g) {
-    unsigned char* st = smem + (g % TF_NSTAGE) * TF_STAGE;
+    if (abl & 4) return;
+    unsigned char* st = smem + (g & (TF_NSTAGE - 1)) * TF_STAGE;
     if (g < NA) {
       const int h = g / KC, kc = g - h * KC;
       const int so = (h * 64 * C + kc * 64) * 2;
+      // (the descriptor is rebuilt from the kernel arguments at every issue: kept live across the kernel it was spilled to
+      //  scratch as a VECTOR value, and every LDS-DMA became a readfirstlane waterfall loop behind an s_waitcnt vmcnt(0))
+      const __amdgpu_buffer_rsrc_t srdQ = __builtin_amdgcn_make_buffer_rsrc((void*)p.wqkv, 0, 0x80000000u, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 6; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdQ, (__attribute__((address_space(3))) void*)(st + (tid + TF_NT * i) * 16), 16,
@@ -80,43 +108,48 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
     } else {
       const int nb = (g - NA) / KC, kc = (g - NA) - nb * KC;
       const int so = (nb * NBO * 32 * C + kc * 64) * 2;
+      const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc((void*)p.wo, 0, 0x80000000u, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NBO; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srdO, (__attribute__((address_space(3))) void*)(st + (tid + TF_NT * i) * 16), 16,
                                                  (int)(vbase + (unsigned)(32 * i * C * 2)), so, 0, 0);
     }
   };
-  // chunk g has landed for every wave, the stage of chunk g - 1 is free: refill it with chunk g + 2
+  // Four stages.  sync_chunk(g), called before the first fragment of chunk g is multiplied: chunk g + 1 has landed for every wave
+  // (so the LAST k-step of chunk g can already read the first fragments of chunk g + 1, ahead of the next barrier), every wave is
+  // past chunk g - 1, whose stage takes chunk g + 3.  Only the loads of chunk g + 2 may still be in flight at the wait.
   auto sync_chunk = [&](int g) {
-    if (g + 1 < NTOT) {
-      if (g + 1 < NA) tf_wait_vmcnt<6>();
+    if (g + 2 < NTOT) {
+      if (g + 2 < NA) tf_wait_vmcnt<6>();
       else tf_wait_vmcnt<NBO>();
     } else {
       tf_wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
-    if (g + 2 < NTOT) issue(g + 2);
+    if (g + 3 < NTOT) issue(g + 3);
   };
   issue(0);
   if (NTOT > 1) issue(1);
+  if (NTOT > 2) issue(2);
 
   // ---- row slots of this wave: slot s = pixel (s / F) of the block, frame s % F; global row (b, f, pixel) = (b F + f) HW + pixel
-  auto slot_row = [&](int s) -> int {                               // (B F HW < 2^31: checked by the entry point)
-    const int pi = s / F, f = s - pi * F;
+  int arow;                                                         // the row of slot l32 (-1: idle slot / beyond the last pixel)
+  {
+    const int pi = l32 / F, f = l32 - pi * F;
     const long long gp = blk * PP + pi;
-    if (pi >= PP || gp >= npix) return -1;
-    const long long b = gp / HW, pos = gp - b * HW;
-    return (int)((b * F + f) * (long long)HW + pos);
-  };
-  const int arow = slot_row(l32);                                   // the row this lane feeds as an operand row
-  int drow[16];                                                     // the rows this lane holds in an accumulator: slot 8(r/4)+4hl+r%4
-  unsigned kmask = 0;                                               // bit r: key slot of register r belongs to the query slot l32's pixel
+    if (pi >= PP || gp >= npix) {
+      arow = -1;
+    } else {
+      const long long b = gp / HW, pos = gp - b * HW;
+      arow = (int)((b * F + f) * (long long)HW + pos);             // (B F HW < 2^31: checked by the entry point)
+    }
+  }
+  unsigned kmask = 0;                                               // bit r: key slot 8(r/4)+4hl+r%4 belongs to the query slot l32's pixel
   {
     const int qp = l32 / F;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int s = 8 * (r >> 2) + 4 * hl + (r & 3);
-      drow[r] = slot_row(s);
       if (s / F == qp && qp < PP) kmask |= 1u << r;
     }
   }
@@ -127,7 +160,7 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
     const bf16_t* xr = (const bf16_t*)p.x + (long long)(arow >= 0 ? arow : 0) * p.ldx + 8 * hl;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) nf[ks] = arow >= 0 ? *(const bf16x8*)(xr + 16 * ks) : zero;
+    for (int ks = 0; ks < KS; ++ks) nf[ks] = (arow >= 0 && !(abl & 2)) ? *(const bf16x8*)(xr + 16 * ks) : zero;
     float s1 = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -158,12 +191,27 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
       nf[ks] = pack8bf(v);
     }
   }
+  // (the x / gamma / beta loads above are younger than the ring's first three chunks and have been waited for: those chunks landed)
+  tf_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
 
-  // ---- phase A: per head q^T, k^T, v -> softmax -> O^T, kept as the A fragments of the output projection
+  // fragment reads: a [192 x 64] (or [NBO*32 x 64]) stage is rows of 128 bytes, 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7);
+  // tile j's fragment of this lane is 4096 j bytes further (the swizzle term does not depend on j).  The Wo image is the same: its
+  // K index comes permuted from the host (see t2v_abi.h), so that the eight head dims an O^T accumulator quad-pair holds are one chunk.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (unsigned)l32 * 128u;
+  const unsigned swz = (unsigned)(l32 >> 1) & 7u;
+  auto frag_addr = [&](int g, int kk) -> unsigned {
+    return lds0 + (unsigned)(g & (TF_NSTAGE - 1)) * (unsigned)TF_STAGE + ((((unsigned)kk * 2u + (unsigned)hl) ^ swz) << 4);
+  };
+
+  // ---- phase A: per head q^T, k^T, v -> softmax -> O^T, kept as the fragments of the output projection
   bf16x8 of[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) of[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   const float sc = p.scale;
+  bf16x8 wc[6], wn[6];                                              // fragments of the k-step being multiplied / of the next one
+  tf_lds_read_n<6>(wc, frag_addr(0, 0));
+  tf_lds_wait<6>(wc);
   for (int h = 0; h < H; ++h) {
     f32x16 aq[2], ak[2], av[2];
 #pragma unroll
@@ -172,20 +220,26 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
       for (int r = 0; r < 16; ++r) aq[j][r] = ak[j][r] = av[j][r] = 0.f;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      sync_chunk(h * KC + kc);
-      const unsigned char* st = smem + ((h * KC + kc) % TF_NSTAGE) * TF_STAGE;
+      const int g = h * KC + kc;
+      sync_chunk(g);
+      if (abl & 8) continue;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        const bool more = kk < 3 || g + 1 < NA;
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) tf_lds_read_n<6>(wn, kk < 3 ? frag_addr(g, kk + 1) : frag_addr(g + 1, 0));
+        __builtin_amdgcn_sched_barrier(0);
         const bf16x8 a = nf[kc * 4 + kk];
-        const int kch = kk * 2 + hl;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const int row = j * 32 + l32;
-          const bf16x8 w = *(const bf16x8*)(st + row * 128 + ((kch ^ ((row >> 1) & 7)) << 4));
-          if (j < 2) aq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, aq[j], 0, 0, 0);                // q^T[d][row]
-          else if (j < 4) ak[j - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, ak[j - 2], 0, 0, 0);   // k^T[d][row]
-          else av[j - 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, av[j - 4], 0, 0, 0);              // v[row][d]
-        }
+        for (int j = 0; j < 2; ++j) aq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[j], a, aq[j], 0, 0, 0);          // q^T[d][row]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ak[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 + j], a, ak[j], 0, 0, 0);      // k^T[d][row]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) av[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wc[4 + j], av[j], 0, 0, 0);      // v[row][d]
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) tf_lds_wait<6>(wn);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wc[j] = wn[j];
       }
     }
     // S^T[key][query] = sum_d k[key][d] q[query][d]: lane = query slot, registers = key slots
@@ -234,43 +288,86 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
       }
   }
 
-  // ---- phase B: out[:, chunk] = O Wo[chunk, :]^T + bo + x
-  const bf16_t* X = (const bf16_t*)p.x;
-  bf16_t* OUT = (bf16_t*)p.out;
+  // ---- phase B: out^T[chunk][row] = Wo[chunk, :] O^T: lane = row slot, registers = four runs of four consecutive columns per tile (+ bo + x)
+  float* stg = (float*)(smem + TF_NSTAGE * TF_STAGE) + wave * (32 * TF_STG_PITCH);
+  int orow[2];                                                      // rows this lane stores in the output pass: slots lane/4 and lane/4 + 16
+#pragma unroll
+  for (int i = 0; i < 2; ++i) orow[i] = __shfl(arow, (lane >> 2) + 16 * i);
+  bf16x8 vc[NBO], vn[NBO];
+  tf_lds_read_n<NBO>(vc, frag_addr(NA, 0));
+  tf_lds_wait<NBO>(vc);
   for (int nb = 0; nb < NOUT; ++nb) {
     f32x16 acc[NBO];
 #pragma unroll
     for (int j = 0; j < NBO; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // the residual rows of this chunk's output pass are requested BEFORE its k-loop where registers allow (C <= 320): issued
+    // inside the pass, every workgroup of the launch waited out their latency at the same time, with its MFMA pipes idle
+    constexpr bool PREX = C <= 320;
+    bf16x8 xpre[PREX ? NBO : 1][2];
+    if constexpr (PREX) {
+      if (!(abl & 1)) {
+#pragma unroll
+        for (int j = 0; j < NBO; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (orow[i] >= 0) xpre[j][i] = *(const bf16x8*)((const bf16_t*)p.x + (long long)orow[i] * p.ldx + nb * NBO * 32 + j * 32 + 8 * (lane & 3));
+      }
+    }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       const int g = NA + nb * KC + kc;
       sync_chunk(g);
-      const unsigned char* st = smem + (g % TF_NSTAGE) * TF_STAGE;
+      if (abl & 8) continue;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        const bool more = kk < 3 || g + 1 < NTOT;
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) tf_lds_read_n<NBO>(vn, kk < 3 ? frag_addr(g, kk + 1) : frag_addr(g + 1, 0));
+        __builtin_amdgcn_sched_barrier(0);
         const bf16x8 a = of[kc * 4 + kk];
 #pragma unroll
-        for (int j = 0; j < NBO; ++j) {
-          const int row = j * 32 + l32, sw = (row >> 1) & 7;
-          // k slots 0..3 <-> head dims 16 kk + 4 hl + (0..3), slots 4..7 <-> 16 kk + 8 + 4 hl + (0..3) (the accumulator layout of O^T)
-          const bf16x4 w0 = *(const bf16x4*)(st + row * 128 + (((2 * kk) ^ sw) << 4) + 8 * hl);
-          const bf16x4 w1 = *(const bf16x4*)(st + row * 128 + (((2 * kk + 1) ^ sw) << 4) + 8 * hl);
-          const bf16x8 w = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < NBO; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[j], a, acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) tf_lds_wait<NBO>(vn);
+#pragma unroll
+        for (int j = 0; j < NBO; ++j) vc[j] = vn[j];
       }
     }
+    // Output pass through a per-wave fp32 staging tile (32 rows x 32 columns): the accumulators hold 4-column runs of 32 DIFFERENT
+    // rows per lane — stored from there, every instruction wrote 16-byte pieces of 32 cache lines (17 of 52 us at C = 320).  Read
+    // back row-wise, a lane owns 8 consecutive columns of a row: 16-byte residual load, 16-byte store, 64 contiguous bytes per row
+    // and 16 rows per instruction; bias, residual and the product meet in fp32, one rounding.
+    if (!(abl & 1)) {
 #pragma unroll
-    for (int j = 0; j < NBO; ++j) {
-      const int c = nb * NBO * 32 + j * 32 + l32;
-      const float bias = p.bo ? p.bo[c] : 0.f;
+      for (int j = 0; j < NBO; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (drow[r] >= 0) {
-          const float v = acc[j][r] + bias + bf2f(X[(long long)drow[r] * p.ldx + c]);
-          OUT[(long long)drow[r] * p.ldo + c] = f2bf(v);
+        for (int q4 = 0; q4 < 4; ++q4)
+          *(f32x4*)(stg + l32 * TF_STG_PITCH + 8 * q4 + 4 * hl) = f32x4{acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]};
+        const int c = nb * NBO * 32 + j * 32 + 8 * (lane & 3);
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bo) {
+          b0 = *(const f32x4*)(p.bo + c);
+          b1 = *(const f32x4*)(p.bo + c + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (lane >> 2) + 16 * i;
+          const f32x4 a0 = *(const f32x4*)(stg + row * TF_STG_PITCH + 8 * (lane & 3));
+          const f32x4 a1 = *(const f32x4*)(stg + row * TF_STG_PITCH + 8 * (lane & 3) + 4);
+          if (orow[i] >= 0) {
+            bf16x8 xr8;
+            if constexpr (PREX) xr8 = xpre[j][i];
+            else xr8 = *(const bf16x8*)((const bf16_t*)p.x + (long long)orow[i] * p.ldx + c);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = a0[e] + b0[e] + bf2f((unsigned short)xr8[e]);
+              v[4 + e] = a1[e] + b1[e] + bf2f((unsigned short)xr8[4 + e]);
+            }
+            *(bf16x8*)((bf16_t*)p.out + (long long)orow[i] * p.ldo + c) = pack8bf(v);
+          }
         }
       }
     }
@@ -279,7 +376,7 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
 
 template <int C, int NBO>
 int tf_launch(const T2VTemporalFused& p, hipStream_t s) {
-  constexpr int SMEM = TF_NSTAGE * TF_STAGE;
+  constexpr int SMEM = TF_SMEM;
   auto kern = temporal_fused_fwd_kernel<C, NBO>;
   static bool attr = false;
   if (!attr) {
@@ -305,8 +402,8 @@ extern "C" int t2v_temporal_fused_fwd(const T2VTemporalFused* pp, t2v_stream_t s
   hipStream_t s = (hipStream_t)stream;
   T2V_CHECK_ARG(t2v_temporal_fused_ok(p.C, p.F), "t2v_temporal_fused_fwd: unsupported width %d / clip length %d", p.C, p.F);
   T2V_CHECK_ARG(p.x && p.out && p.wqkv && p.wo && p.gamma && p.beta, "t2v_temporal_fused_fwd: null operand");
-  T2V_CHECK_ARG(p.B >= 1 && p.HW >= 1 && p.ldx >= p.C && p.ldo >= p.C && (p.ldx & 7) == 0, "t2v_temporal_fused_fwd: bad geometry");
-  T2V_CHECK_ARG((((uintptr_t)p.x | (uintptr_t)p.wqkv | (uintptr_t)p.wo | (uintptr_t)p.gamma | (uintptr_t)p.beta) & 15) == 0,
+  T2V_CHECK_ARG(p.B >= 1 && p.HW >= 1 && p.ldx >= p.C && p.ldo >= p.C && (p.ldx & 7) == 0 && (p.ldo & 7) == 0, "t2v_temporal_fused_fwd: bad geometry");
+  T2V_CHECK_ARG((((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.bo | (uintptr_t)p.wqkv | (uintptr_t)p.wo | (uintptr_t)p.gamma | (uintptr_t)p.beta) & 15) == 0,
                 "t2v_temporal_fused_fwd: operands must be 16-byte aligned");
   T2V_CHECK_ARG((long long)p.B * p.F * p.HW < (1ll << 31), "t2v_temporal_fused_fwd: too many rows");
   if ((long long)p.B * p.HW == 0) return T2V_OK;

@@ -1602,18 +1602,35 @@ def attention(q, k, v, heads, qlay, klay, scale=0.125, causal=False):
 
 # --------------------------------------------------------------------------- fused temporal unit (forward only)
 _temporal_fused = os.environ.get("T2V_TEMPORAL_FUSED", "1") != "0"
+_temporal_ablate = [0]          # measurement only (scripts/temporal_fused_probe.py): T2VTemporalFused.ablate of the next launches
 
 
-def temporal_fused_ok(C_, frames):
+_temporal_fused_maxc = int(os.environ.get("T2V_TEMPORAL_FUSED_MAXC", "512"))
+
+
+def temporal_fused_ok(C_, frames, policy=True):
     """The library has a one-launch kernel for `LN -> q,k,v -> FxF softmax -> PV -> out-proj -> + residual` at this width / clip
-    length (csrc/temporal_fused.hip) and the switch T2V_TEMPORAL_FUSED is on."""
-    return _temporal_fused and bool(nv.lib().t2v_temporal_fused_ok(int(C_), int(frames)))
+    length (csrc/temporal_fused.hip), the switch T2V_TEMPORAL_FUSED is on and — `policy` — the measured dispatch rule says it wins:
+    widths up to 512 (profiles/r06_temporal_fused_probe.txt: 49 vs 109 us at C = 320, 117 vs 168 us at C = 512 on the C2 grid; the
+    C = 640 kernel holds LN(x) AND the attention output of all ten heads in registers, spills, and loses to the separate launches at
+    both grids: 168 vs 79 us, 359 vs 284 us).  T2V_TEMPORAL_FUSED_MAXC moves the bound."""
+    if not (_temporal_fused and bool(nv.lib().t2v_temporal_fused_ok(int(C_), int(frames)))):
+        return False
+    return (not policy) or int(C_) <= _temporal_fused_maxc
+
+
+def temporal_fused_prepare_wo(wo):
+    """The output-projection weight in the layout `t2v_temporal_fused_fwd` reads (include/t2v_abi.h): bf16 [C, C] with the INPUT index
+    permuted inside every group of 16 — stored position 16 g + 8 a + 4 b + c holds input 16 g + 8 b + 4 a + c (a, b in {0, 1},
+    c in 0..3): the eight head dims one lane of an O^T accumulator holds per k-step become one 16-byte chunk."""
+    n, k = wo.shape
+    return wo.detach().to(BF16).view(n, k // 16, 2, 2, 4).transpose(2, 3).reshape(n, k).contiguous()
 
 
 def temporal_attention_fused(x, gamma, beta, eps, wqkv, wo, bo, batch, frames, hw, scale=0.125):
     """out = x + softmax_F((LN(x) Wq^T)(LN(x) Wk^T)^T scale)(LN(x) Wv^T) Wo^T + bo in ONE launch, nothing kept for a backward
     (include/t2v_abi.h `t2v_temporal_fused_fwd`).  x: [batch*frames*hw, C] bf16 token matrix, rows (b, f, pixel); wqkv: bf16 [3C, C]
-    (rows of to_q, to_k, to_v), wo: bf16 [C, C]."""
+    (rows of to_q, to_k, to_v), wo: bf16 [C, C] as `temporal_fused_prepare_wo` lays it out."""
     if torch.is_grad_enabled() and (x.requires_grad or wqkv.requires_grad or wo.requires_grad):
         raise RuntimeError("t2v_amd: temporal_attention_fused is forward-only; call it under torch.no_grad()")
     x = _mat(x, "x")
@@ -1630,6 +1647,7 @@ def temporal_attention_fused(x, gamma, beta, eps, wqkv, wo, bo, batch, frames, h
     d.bo, d.gamma, d.beta = nv.ptr(bo32), g32.data_ptr(), b32.data_ptr()
     d.eps, d.scale = float(eps), float(scale)
     d.B, d.F, d.HW, d.C = int(batch), int(frames), int(hw), int(Cc)
+    d.ablate = _temporal_ablate[0]
     nv.call("t2v_temporal_fused_fwd", C.byref(d), nv.stream())
     return out
 

@@ -394,7 +394,7 @@ def _temporal_unit_fused(norm, attn, t, qlay):
     tag = tuple(p[0] for p in parts)
     hit = attn.__dict__.get("_t2v_fused_w")
     if hit is None or hit[0] != tag or hit[1].device != t.device:
-        hit = (tag, torch.cat([p[1]() for p in parts[:3]], dim=0).contiguous(), parts[3][1]())
+        hit = (tag, torch.cat([p[1]() for p in parts[:3]], dim=0).contiguous(), F.temporal_fused_prepare_wo(parts[3][1]()))
         attn.__dict__["_t2v_fused_w"] = hit
     return F.temporal_attention_fused(t, norm.weight, norm.bias, norm.eps, hit[1], hit[2], parts[3][2], qlay.nbatch // hw, frames, hw,
                                       attn.scale)

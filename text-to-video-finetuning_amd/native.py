@@ -106,7 +106,7 @@ class TemporalFused(C.Structure):
     _fields_ = [
         ("x", c_void_p), ("ldx", c_ll), ("out", c_void_p), ("ldo", c_ll), ("wqkv", c_void_p), ("wo", c_void_p),
         ("bo", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("scale", c_float),
-        ("B", c_int), ("F", c_int), ("HW", c_int), ("C", c_int),
+        ("B", c_int), ("F", c_int), ("HW", c_int), ("C", c_int), ("ablate", c_int),
     ]
 
 
