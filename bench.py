@@ -477,6 +477,24 @@ def temporal_fused_forward(unet, frames, H, W, dev):
         finally:
             F._temporal_fused = was
         rel = float((out_f.float() - out_s.float()).norm() / out_s.float().norm())
+        # the same call as the sampler issues it: captured once, replayed per timestep (pipelines.TextToVideoSampler)
+        ms_graph = None
+        try:
+            fwd()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                fwd()
+            gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                gr.replay()
+            torch.cuda.synchronize()
+            ms_graph = (time.perf_counter() - t0) / 5 * 1e3
+            del gr
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] capturing the sampling forward failed: {type(e).__name__}: {e}", file=sys.stderr)
     finally:
         nv.call = orig_call
         unet.train(was_training)
@@ -501,8 +519,9 @@ def temporal_fused_forward(unet, frames, H, W, dev):
                           for Cc, a in sorted(by.items())},
             "policy": "widths <= 512 take the one-launch kernel (functional.temporal_fused_ok); the C = 1280 levels have 4 - 16 row tiles "
                       "per launch and stay on separate launches, C = 640 loses to them (registers)",
-            "sampling_unet_forward_ms": {"one_launch_units": round(ms_fused, 2), "separate_launches": round(ms_sep, 2),
-                                         "eager, host-timed, batch 2 (CFG pair)": True},
+            "sampling_unet_forward_ms": {"graph_replay_one_launch_units": None if ms_graph is None else round(ms_graph, 2),
+                                         "eager_one_launch_units": round(ms_fused, 2), "eager_separate_launches": round(ms_sep, 2),
+                                         "note": "batch 2 (CFG pair), host-timed over 5 calls; the eager forms are bound by the host's launch path"},
             "one_launch_vs_separate_relerr": round(rel, 6)}
 
 

@@ -16,6 +16,7 @@ import pytest
 import torch
 
 import parity_utils as pu
+from conftest import relerr
 from parity_utils import FLOOR_FACTOR, floor_row as _floor, record as _record, set_lora_up as _set_lora_up
 
 pytestmark = pytest.mark.gpu
@@ -195,6 +196,50 @@ def test_default_train_mode_lora_on_the_shipped_grids(frames, h, w, r):
     assert cmp["rel"] < 0.12 and cmp["cos"] > 0.99
     assert big["worst_cos"] > 0.9 and cmp["worst_cos"] > 0.8
     assert all(float(g.abs().max()) > 0 for n, g in g_dut.items()), "every factor receives a gradient"
+
+
+@pytest.mark.parametrize("frames", [4, 16])
+def test_no_grad_forward_with_live_lora_branches_matches_oracle(frames):
+    """The forward-only UNet call of sampling / validation (train.py:895-958: `unet.eval()`, no grad) with LIVE LoRA branches on all
+    574-equivalent layers of the toy model: every cloneofsimo wrapper multiplies by its folded weight W + s up down (one launch,
+    models/leaves.py `_folded_weight`), the temporal attention units take the one-launch kernel (csrc/temporal_fused.hip) — against
+    the CPU fp32 oracle's `base(x) + up(down(x)) * scale` on the same weights, and against the same native module's grad-enabled
+    forward (separate branch launches).  Then the factors move WITHOUT a version bump (what t2v_adamw does): the folded copies
+    must follow through functional.weights_epoch."""
+    import parity_utils as pu
+    import t2v_amd.functional as F
+    ounet, ovae, _ = pu.build_oracle(False, 4, 0.3)
+    dunet, _ = pu.build_native(ounet, ovae, False, 4)
+    ounet.eval(); dunet.eval()
+    g = torch.Generator().manual_seed(31 + frames)
+    x, t, ehs = torch.randn(2, 4, frames, 16, 16, generator=g), torch.randint(0, 1000, (2,), generator=g), torch.randn(2, 77, 64, generator=g)
+    calls = []
+    real = F.temporal_attention_fused
+    F.temporal_attention_fused = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            yr = ounet(x, t, ehs).sample
+            y0 = dunet(x.cuda(), t.cuda(), ehs.cuda()).sample
+    finally:
+        F.temporal_attention_fused = real
+    assert len(calls) == 34, len(calls)                          # 17 temporal transformers x (attn1, attn2)
+    y1 = dunet(x.cuda(), t.cuda(), ehs.cuda()).sample.detach()    # grad mode: base + down + up launches, separate attention launches
+    e0, e1, e01 = relerr(y0, yr), relerr(y1, yr), relerr(y0, y1)
+    print(f"no-grad LoRA forward ({frames} frames): folded vs oracle {e0:.3e}, branch launches vs oracle {e1:.3e}, folded vs branch {e01:.3e}")
+    assert e0 < 6e-2 and e1 < 6e-2 and e01 < 6e-2
+    # an optimiser-kernel style update: values move, no version counter does
+    for n_, p_ in dunet.named_parameters():
+        if "lora_up" in n_:
+            p_.data.mul_(-1.0)
+    for n_, p_ in ounet.named_parameters():
+        if "lora_up" in n_:
+            p_.data.mul_(-1.0)
+    F.note_weights_changed()
+    with torch.no_grad():
+        yr2 = ounet(x, t, ehs).sample
+        y2 = dunet(x.cuda(), t.cuda(), ehs.cuda()).sample
+    assert relerr(yr2, yr) > 3 * relerr(y2, yr2), "the flipped branches change the output visibly"
+    assert relerr(y2, yr2) < 6e-2, "folded weights did not follow the update"
 
 
 def test_toy_rank_beyond_the_merge_window_trains_and_matches_oracle():

@@ -96,6 +96,8 @@ def test_sampler_with_the_native_unet_follows_the_oracle_unet_under_cfg():
     # and the guidance really is in the loop: without the negative prompt the trajectory differs visibly
     out_nocfg = TextToVideoSampler(ref, DPMSolverMultistepScheduler())(pos, None, latents=lat.clone(), num_inference_steps=3, guidance_scale=1.0)
     print(f"sampler (CFG 4, 3 DPM-Solver++ steps): final latents native vs oracle relerr {e:.3e}; oracle with vs without CFG {relerr(out_nocfg, out_ref):.3e}")
+    from parity_utils import record as _record
+    _record(test="sampler_cfg_native_vs_oracle", relerr=e, cfg_vs_nocfg=relerr(out_nocfg, out_ref))
     assert e < 6e-2
     assert relerr(out_nocfg, out_ref) > 2 * e            # (measured 0.080 against e = 0.035)
     # the windowed / rotated long-video loop (inference.py:199-262) around the native UNet against the same loop around the oracle
@@ -104,6 +106,51 @@ def test_sampler_with_the_native_unet_follows_the_oracle_unet_under_cfg():
     w_dut = TextToVideoSampler(dut, DPMSolverMultistepScheduler())(pos.cuda(), neg.cuda(), latents=lat.cuda(), window_size=4, rotate=True,
                                                                    generator=gw(), **kw)
     assert relerr(w_dut, w_ref) < 6e-2
+
+
+def test_sampler_graph_replay_equals_eager_and_follows_weight_updates():
+    """The sampler's UNet call is captured into a HIP graph on first use and replayed at every later timestep (pipelines.py): the
+    trajectory must equal the eager one, for the plain loop and for the windowed loop (two window shapes = two captures), and a
+    capture must not outlive the weights it was made for — neither a torch-visible update (version counters) nor one made by this
+    library's own optimiser kernels (functional.weights_epoch; emulated through `.data`, which moves no version counter)."""
+    import t2v_amd.functional as F
+    from oracle.unet3d import UNet3DConditionModel as OUNet
+    from oracle.weights import randomize_temporal_conv4
+    from t2v_amd.models.unet_3d_condition import UNet3DConditionModel
+    from t2v_amd.pipelines import TextToVideoSampler
+    from t2v_amd.schedulers import DPMSolverMultistepScheduler
+    torch.manual_seed(21)
+    ref = OUNet(**SMALL).eval(); randomize_temporal_conv4(ref)
+    dut = UNet3DConditionModel(**SMALL); dut.load_state_dict(ref.state_dict(), strict=True)
+    dut = dut.cuda().eval()
+    g = torch.Generator().manual_seed(22)
+    lat = torch.randn(1, 4, 6, 16, 16, generator=g).cuda()
+    pos, neg = torch.randn(1, 77, 64, generator=g).cuda(), torch.randn(1, 77, 64, generator=g).cuda()
+    kw = dict(num_inference_steps=4, guidance_scale=5.0)
+    eager = TextToVideoSampler(dut, DPMSolverMultistepScheduler(), graph=False)
+    replay = TextToVideoSampler(dut, DPMSolverMultistepScheduler(), graph=True)
+    a, b = eager(pos, neg, latents=lat.clone(), **kw), replay(pos, neg, latents=lat.clone(), **kw)
+    assert len(replay._graphs) == 1
+    assert relerr(b, a) < 1e-6, relerr(b, a)
+    gw = lambda: torch.Generator().manual_seed(5)
+    a = eager(pos, neg, latents=lat.clone(), window_size=4, rotate=True, generator=gw(), **kw)
+    b = replay(pos, neg, latents=lat.clone(), window_size=4, rotate=True, generator=gw(), **kw)
+    assert len(replay._graphs) == 3                              # full clip, 4-frame window, 2-frame tail window
+    assert relerr(b, a) < 1e-6, relerr(b, a)
+    w = dut.conv_in.weight
+    with torch.no_grad():
+        w.mul_(1.5)                                              # a torch-visible update
+    a, b = eager(pos, neg, latents=lat.clone(), **kw), replay(pos, neg, latents=lat.clone(), **kw)
+    assert relerr(b, a) < 1e-6, "stale capture after an in-place parameter update"
+    tq = dut.transformer_in.transformer_blocks[0].attn1.to_q.weight
+    tq.data.mul_(0.5)                                            # moves no version counter (what t2v_adamw on the flat buffer does) ...
+    tq.requires_grad_(True)
+    F.note_weights_changed()                                     # ... the optimiser step announces it instead
+    try:
+        a, b = eager(pos, neg, latents=lat.clone(), **kw), replay(pos, neg, latents=lat.clone(), **kw)
+    finally:
+        tq.requires_grad_(False)
+    assert relerr(b, a) < 1e-6, "stale capture / stale folded temporal weights after an optimiser-kernel update"
 
 
 def _build(r=4, lora_up_scale=0.05):

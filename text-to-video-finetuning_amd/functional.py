@@ -83,6 +83,17 @@ LINEAR = ConvCfg()
 
 
 # --------------------------------------------------------------------------- weight preparation (bf16 GEMM layouts)
+# Parameters that train are updated by this library's own kernels (t2v_adamw on the flat buffer, inside replayed graphs): torch's
+# version counters never move.  Every update path bumps this epoch instead (FlatAdamW.step / load_state_dict); caches of values
+# DERIVED from trainable parameters outside the trainer's own refresh (folded LoRA weights of the forward-only temporal unit, the
+# sampler's captured UNet call) carry it in their tags.
+weights_epoch = [0]
+
+
+def note_weights_changed():
+    weights_epoch[0] += 1
+
+
 def clear_weight_cache(model=None):
     """Drop cached prepared copies (they live on the Parameter objects themselves, so they die with the model)."""
     if model is not None:

@@ -112,8 +112,31 @@ def _low_rank_product(B, A):
     return F.conv_linear(Bb.contiguous(), A.t(), None, LINEAR)[:, : A.shape[1]].float()
 
 
+_fold_no_grad = __import__("os").environ.get("T2V_FOLD_NO_GRAD", "1") != "0"     # (0: base + down + up launches in no-grad calls too)
+
+
 def _drop_p(mod):
     return float(mod.p) if (isinstance(mod, nn.Dropout) and mod.training) else 0.0
+
+
+def _folded_weight(mod, base):
+    """`W + scale * up @ down` of a cloneofsimo wrapper (Linear / Conv2d / Conv3d: utils/lora.py:57-62,134-139,211-216 with the
+    Dropout inactive and no selector) as a FROZEN bf16 Parameter in the base weight's shape — what a no-grad forward (sampling,
+    validation: train.py:895-958) multiplies by, one launch per layer instead of base + down + up.  Cached on the wrapper; the tag
+    carries the tensors' version counters and, for factors that train, functional.weights_epoch (this library's optimiser kernels
+    move no version counter).  The low-rank product runs on this library's GEMM (bf16 factors, fp32 accumulation), the sum in fp32."""
+    w, u, d, sc = base.weight, mod.lora_up.weight, mod.lora_down.weight, float(mod.scale)
+    tag = (w.data_ptr(), w._version, u.data_ptr(), u._version, d.data_ptr(), d._version, sc, str(w.device),
+           F.weights_epoch[0] if (w.requires_grad or u.requires_grad or d.requires_grad) else -1)
+    hit = mod.__dict__.get("_t2v_folded")
+    if hit is None or hit[0] != tag:
+        with torch.no_grad():
+            r = d.shape[0]
+            delta = _low_rank_product(u.detach().reshape(u.shape[0], r), d.detach().reshape(r, -1))
+            wf = (w.detach().float() + sc * delta.view(w.shape)).to(BF16)
+        hit = (tag, nn.Parameter(wf, requires_grad=False))
+        mod.__dict__["_t2v_folded"] = hit
+    return hit[1]
 
 
 def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
@@ -128,6 +151,10 @@ def run_layer(mod, x, cfg=LINEAR, rowbias=None, residual=None, colsum=False):
         entry = getattr(mod, "_t2v_bank", None)
         sel = getattr(mod, "selector", None)
         p = _drop_p(getattr(mod, "dropout", None))
+        if (not torch.is_grad_enabled() and p == 0.0 and (sel is None or isinstance(sel, nn.Identity)) and _fold_no_grad
+                and mod.lora_up.weight.shape[0] % 8 == 0 and base.weight.shape[1] % 8 == 0):
+            # forward-only call with the branch's Dropout inactive: the folded weight, one launch
+            return F.conv_linear(x, _folded_weight(mod, base), base.bias, cfg, rowbias, residual, colsum=colsum)
         if (entry is not None and not base.weight.requires_grad
                 and (base.bias is None or not base.bias.requires_grad) and (sel is None or isinstance(sel, nn.Identity))
                 and torch.is_grad_enabled()):
@@ -357,7 +384,8 @@ def _effective_weight(mod):
     in a forward: W, or W + scale * up @ down (utils/lora.py:57-62 with the Dropout in eval mode).  None: not expressible."""
     if isinstance(mod, nn.Linear) and not hasattr(mod, "lora_A"):
         w = mod.weight
-        return ("lin", w.data_ptr(), w._version), (lambda: F.prepared_weight(w, "fwd")), mod.bias
+        # (a weight that trains moves under this library's own optimiser kernels without a version bump: functional.weights_epoch)
+        return ("lin", w.data_ptr(), w._version, F.weights_epoch[0] if w.requires_grad else -1), (lambda: F.prepared_weight(w, "fwd")), mod.bias
     base = getattr(mod, "linear", None)
     if base is None or not (hasattr(mod, "lora_down") and hasattr(mod, "lora_up")) or _drop_p(getattr(mod, "dropout", None)) > 0.0:
         return None
@@ -367,12 +395,9 @@ def _effective_weight(mod):
     w, u, d, sc = base.weight, mod.lora_up.weight, mod.lora_down.weight, float(mod.scale)
     if w.shape[0] % 8 or w.shape[1] % 8:
         return None
-    tag = ("lora", w.data_ptr(), w._version, u.data_ptr(), u._version, d.data_ptr(), d._version, sc)
-
-    def make():
-        with torch.no_grad():
-            return (w.detach().float() + sc * _low_rank_product(u.detach(), d.detach())).to(BF16).contiguous()
-    return tag, make, base.bias
+    tag = ("lora", w.data_ptr(), w._version, u.data_ptr(), u._version, d.data_ptr(), d._version, sc,
+           F.weights_epoch[0] if (w.requires_grad or u.requires_grad or d.requires_grad) else -1)
+    return tag, (lambda: F.prepared_weight(_folded_weight(mod, base), "fwd")), base.bias
 
 
 def _temporal_unit_fused(norm, attn, t, qlay):

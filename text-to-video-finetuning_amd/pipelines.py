@@ -19,17 +19,63 @@ def primes_up_to(n):
 
 
 class TextToVideoSampler:
-    def __init__(self, unet, scheduler=None, vae=None):
+    """`graph` (default: on, T2V_SAMPLER_GRAPH=0 turns it off): the UNet call of a denoising step — the same kernels with the same
+    shapes at every one of the 25 - 50 timesteps — is captured into a HIP graph on its first use and replayed afterwards; an eager
+    no-grad forward of the 1.7B UNet is ~1 700 launches whose ISSUE takes longer than their execution (bench.py
+    `sampling_unet_forward_ms`).  The capture is keyed by the call's shapes and is dropped when any UNet parameter has changed
+    since (sampling between training steps, train.py:895-958) or the module is in train mode (active dropout draws host-seeded
+    masks: eager only)."""
+
+    def __init__(self, unet, scheduler=None, vae=None, graph=None):
+        import os
         self.unet, self.vae = unet, vae
         self.scheduler = scheduler or DPMSolverMultistepScheduler()
+        self.graph = ((os.environ.get("T2V_SAMPLER_GRAPH", "1") != "0") if graph is None else bool(graph)) and isinstance(unet, torch.nn.Module)
+        self._graphs = {}
+        self._weights_tag = None
+
+    def _unet_eps(self, xin, ts, ehs):
+        return self.unet(xin, ts, encoder_hidden_states=ehs).sample
+
+    def _weights_signature(self):
+        # torch's version counters see load_state_dict / a torch optimiser; this library's own optimiser kernels (also inside
+        # replayed graphs) are seen through functional.weights_epoch
+        from . import functional as F
+        return (sum(p._version for p in self.unet.parameters()), sum(1 for _ in self.unet.parameters()), F.weights_epoch[0])
+
+    def _eps_replayed(self, xin, t, ehs):
+        """eps of the captured UNet call, or None when this call has to run eagerly (CPU oracle module, train mode)."""
+        if not self.graph or not xin.is_cuda or self.unet.training or not hasattr(torch.cuda, "CUDAGraph"):
+            return None
+        key = (tuple(xin.shape), xin.dtype, tuple(ehs.shape), ehs.dtype, xin.device.index)
+        hit = self._graphs.get(key)
+        if hit is None:
+            st = {"x": xin.clone(), "t": torch.full((xin.shape[0],), int(t), dtype=torch.long, device=xin.device), "ehs": ehs.clone()}
+            self._unet_eps(st["x"], st["t"], st["ehs"])          # warm-up: prepared / folded weight copies, workspaces
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["eps"] = self._unet_eps(st["x"], st["t"], st["ehs"])
+            hit = (g, st)
+            self._graphs[key] = hit
+        g, st = hit
+        st["x"].copy_(xin)
+        st["t"].fill_(int(t))
+        st["ehs"].copy_(ehs)
+        g.replay()
+        return st["eps"]
 
     def _eps(self, x, t, ehs, cfg, guidance_scale, dev):
         xin = torch.cat([x, x], 0) if cfg else x                               # CFG: unconditional + conditional in one forward
-        ts = torch.full((xin.shape[0],), int(t), dtype=torch.long, device=dev)
-        eps = self.unet(xin, ts, encoder_hidden_states=ehs).sample
+        eps = self._eps_replayed(xin, t, ehs)
+        if eps is None:
+            ts = torch.full((xin.shape[0],), int(t), dtype=torch.long, device=dev)
+            eps = self._unet_eps(xin, ts, ehs)
         if cfg:
             e_u, e_c = eps.chunk(2)
             eps = e_u + guidance_scale * (e_c - e_u)
+        else:
+            eps = eps.clone()                                                   # (a replay overwrites the captured output)
         return eps.to(x.dtype)
 
     @torch.no_grad()
@@ -38,6 +84,13 @@ class TextToVideoSampler:
                  window_size=None, rotate=False, vae_batch_size=8, init_weight=0.0):
         b = prompt_embeds.shape[0]
         dev = prompt_embeds.device
+        if self.graph and self._graphs:
+            tag = self._weights_signature()
+            if tag != self._weights_tag:                 # a parameter was updated / reloaded since the captures were made
+                self._graphs.clear()
+            self._weights_tag = tag
+        elif self.graph:
+            self._weights_tag = self._weights_signature()
         cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
         gdev = generator.device if generator is not None else "cpu"
         if latents is None:

@@ -264,6 +264,8 @@ class FlatAdamW:
             nv.call("t2v_sumsq", self.flat_g.data_ptr(), self.numel, self.sumsq.data_ptr(), self._sumsq_ws.data_ptr(), s)
         lr = self.lr * (self.lr_schedule(self.steps_done) if self.lr_schedule is not None else 1.0)
         self.steps_done += 1
+        from .functional import note_weights_changed
+        note_weights_changed()
         nv.call("t2v_adamw", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                 self.exp_avg_sq.data_ptr(), self.numel, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 self.sumsq.data_ptr() if clip else None, float(self.max_grad_norm or 0.0), float(grad_scale),
