@@ -59,14 +59,14 @@ __device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, lon
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  bf16x8 rb[2], rs[NS];
+  bf16x8 rbA[2], rsA[NS], rbB[2], rsB[NS];          // two steps of operands in flight (round 6, see the loop below)
   const bool masked = P.mp > 0.f;
   const DropKey dkey = drop_key(masked ? eff_seed(P.mseed, P.mepoch) : 0ull, P.mp);
   if (masked) alpha *= 1.f / (1.f - P.mp);         // the kept elements' 1/(1-p) rides in the output scale: the operand is a bit select
   const int srow = (tid & 127) >> 1, shalf = tid & 1, stap0 = tid >> 7;
   const unsigned hw = (unsigned)(g.Hv * g.Wv);
 
-  auto fetch = [&](long long row0) {
+  auto fetch = [&](long long row0, bf16x8 (&rb)[2], bf16x8 (&rs)[NS]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int id = tid + 256 * i, row = id >> 3, cc = id & 7;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, lon
       }
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](const bf16x8 (&rb)[2], const bf16x8 (&rs)[NS]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int id = tid + 256 * i, row = id >> 3, cc = id & 7;
@@ -138,12 +138,23 @@ __device__ __forceinline__ void wgrad_body(const Prob& P, long long r_begin, lon
     }
   };
 
-  fetch(r_begin);
-  for (long long row0 = r_begin; row0 < r_end; row0 += KR) {
+  // Two steps of global loads stay in flight per workgroup (round 6).  With one (rounds 1 - 5) a workgroup had 8 KB of the wide
+  // operand outstanding, ~40 KB per CU at the five workgroups the LDS footprint admits: 10 MB chip-wide against the ~16 MB that
+  // 8 TB/s x ~2 us of latency asks for — the batched launches of a C2 step streamed at 3.4 TB/s (profiles/r06_mid_window.txt:
+  // 4.68 ms for 15.8 GB).
+  fetch(r_begin, rbA, rsA);
+  if (r_begin + KR < r_end) fetch(r_begin + KR, rbB, rsB);
+  for (long long row0 = r_begin; row0 < r_end; row0 += 2 * KR) {
     __syncthreads();
-    stash();
+    stash(rbA, rsA);
     __syncthreads();
-    if (row0 + KR < r_end) fetch(row0 + KR);
+    if (row0 + 2 * KR < r_end) fetch(row0 + 2 * KR, rbA, rsA);
+    compute();
+    if (row0 + KR >= r_end) break;
+    __syncthreads();
+    stash(rbB, rsB);
+    __syncthreads();
+    if (row0 + 3 * KR < r_end) fetch(row0 + 3 * KR, rbB, rsB);
     compute();
   }
   const int col = c0 + 16 * w + li;
@@ -290,8 +301,13 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(Args a) {
 // Many layers in ONE launch (t2v_lora_wgrad_batch): a device table of per-pass arguments + the first workgroup of every
 // pass; a workgroup finds its pass by binary search and runs the same body.  The per-layer launches of a C2 step are
 // 568 kernels of ~15 us whose ramp and tail dominate (most layers move < 10 MB); batched they stream back to back.
-__global__ __launch_bounds__(256) void lora_wgrad_batch_kernel(const Args* __restrict__ jobs, const int* __restrict__ first, int njobs) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[KR * PITCH + 9 * KR * SP];
+// Round 6: the table is split by window size.  MAXTAPS = 1 (Linear / 1x1 layers: most of a step's passes) compiles the one-tap
+// body only — 86 registers and 12 KB of LDS instead of the nine-tap body's 180 / 28 KB, i.e. five workgroups per CU with two
+// steps of loads in flight each instead of three with one (24 KB -> 80 KB outstanding per CU); MAXTAPS = 9 takes the passes of
+// the windowed layers (their dU tiles run the one-tap body there).
+template <int MAXTAPS>
+__global__ __launch_bounds__(256, 3) void lora_wgrad_batch_kernel(const Args* __restrict__ jobs, const int* __restrict__ first, int njobs) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KR * PITCH + MAXTAPS * KR * SP];
   int lo = 0, hi = njobs - 1;
   const int b = (int)blockIdx.x;
   while (lo < hi) {                          // largest j with first[j] <= b (wave-uniform: scalar loads)
@@ -310,10 +326,15 @@ __global__ __launch_bounds__(256) void lora_wgrad_batch_kernel(const Args* __res
     wgrad_body<1>(a.u, r_begin, r_end, tile * 64, a.g, a.rk, a.alpha, smem);
     return;
   }
-  const int c0 = (tile - a.u.tiles) * 64, taps = a.g.KH * a.g.KW;
-  if (taps == 1) wgrad_body<1>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
-  else if (taps == 3) wgrad_body<3>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
-  else wgrad_body<9>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+  const int c0 = (tile - a.u.tiles) * 64;
+  if constexpr (MAXTAPS == 1) {
+    wgrad_body<1>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+  } else {
+    const int taps = a.g.KH * a.g.KW;
+    if (taps == 1) wgrad_body<1>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+    else if (taps == 3) wgrad_body<3>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+    else wgrad_body<9>(a.d, r_begin, r_end, c0, a.g, a.rk, a.alpha, smem);
+  }
 }
 
 // argument checks + the passes (one per 16 rank rows) of one layer; returns the number of passes appended or a negative code
@@ -370,29 +391,52 @@ extern "C" int t2v_lora_wgrad_batch(const T2VLoraWgrad* descs, int nlayers, void
                 table_bytes, nlayers);
   // staging layout: [2*nlayers] Args, then [2*nlayers] first-workgroup indices (host builds it, ONE async copy brings it over;
   // inside a stream capture the copy becomes a graph node that re-reads the same pinned staging buffer at every replay)
+  // (round 6: two tables — the passes of one-tap layers in front, those of windowed layers behind them, each with its own
+  //  first-workgroup indices; one launch per non-empty table)
   Args* jobs = (Args*)host_staging;
   int* first = (int*)((unsigned char*)host_staging + (size_t)nlayers * 2 * sizeof(Args));
-  int njobs = 0;
-  long long total = 0;
+  auto light = [&](const T2VLoraWgrad& d) { return !d.conv || d.geom.KH * d.geom.KW == 1; };
+  int nl = 0;
+  for (int l = 0; l < nlayers; ++l)
+    if (light(descs[l])) nl += (descs[l].rp + 15) / 16;
+  int il = 0, ih = nl;
+  long long tl = 0, th = 0;
   for (int l = 0; l < nlayers; ++l) {
     int blocks[2];
-    const int n = wgrad_passes(descs[l], jobs + njobs, blocks);
+    Args tmp[2];
+    const int n = wgrad_passes(descs[l], tmp, blocks);
     if (n < 0) return n;
+    const bool lt = light(descs[l]);
     for (int q = 0; q < n; ++q) {
-      first[njobs + q] = (int)total;
-      total += blocks[q];
+      int& idx = lt ? il : ih;
+      long long& tot = lt ? tl : th;
+      jobs[idx] = tmp[q];
+      first[idx] = (int)tot;
+      tot += blocks[q];
+      ++idx;
     }
-    njobs += n;
   }
-  T2V_CHECK_ARG(total < (1LL << 31), "t2v_lora_wgrad_batch: too many workgroups");
+  T2V_CHECK_ARG(il == nl && ih <= 2 * nlayers, "t2v_lora_wgrad_batch: pass count mismatch");
+  const int nh = ih - nl;
+  T2V_CHECK_ARG(tl < (1LL << 31) && th < (1LL << 31), "t2v_lora_wgrad_batch: too many workgroups");
   const size_t args_bytes = (size_t)nlayers * 2 * sizeof(Args);
-  if (hipMemcpyAsync(device_table, host_staging, args_bytes + (size_t)njobs * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream) !=
+  if (hipMemcpyAsync(device_table, host_staging, args_bytes + (size_t)ih * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream) !=
       hipSuccess) {
     t2v_set_error("t2v_lora_wgrad_batch: staging copy failed: %s", hipGetErrorString(hipGetLastError()));
     return T2V_ELAUNCH;
   }
-  T2V_LAUNCH(lora_wgrad_batch_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const Args*)device_table,
-                     (const int*)((const unsigned char*)device_table + args_bytes), njobs);
+  const Args* djobs = (const Args*)device_table;
+  const int* dfirst = (const int*)((const unsigned char*)device_table + args_bytes);
+  // (measurement hook: the start event goes to the first launch, the stop event to the last)
+  if (nl > 0 && nh > 0) {
+    T2V_LAUNCH_FIRST(lora_wgrad_batch_kernel<1>, dim3((unsigned)tl), dim3(256), 0, (hipStream_t)stream, djobs, dfirst, nl);
+    T2V_CHECK_LAUNCH();
+    T2V_LAUNCH_LAST(lora_wgrad_batch_kernel<9>, dim3((unsigned)th), dim3(256), 0, (hipStream_t)stream, djobs + nl, dfirst + nl, nh);
+  } else if (nl > 0) {
+    T2V_LAUNCH(lora_wgrad_batch_kernel<1>, dim3((unsigned)tl), dim3(256), 0, (hipStream_t)stream, djobs, dfirst, nl);
+  } else {
+    T2V_LAUNCH(lora_wgrad_batch_kernel<9>, dim3((unsigned)th), dim3(256), 0, (hipStream_t)stream, djobs + nl, dfirst + nl, nh);
+  }
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
