@@ -673,7 +673,7 @@ def test_reloaded_base_weights_reach_the_merged_path():
 def test_trainer_state_round_trip_resumes_the_same_trajectory():
     """save -> load -> identical next step.  Two steps of the default train mode (dropout active), `state_dict()`,
     one more step; a FRESH trainer on a copy of the model as it stood after step 2 loads the state and must reproduce step 3
-    bit for bit — AdamW moments and step counter, LR-schedule position, the host dropout step and the device dropout epoch all
+    to the last bits the step's own fp32 atomics leave open (bounds below) — AdamW moments and step counter, LR-schedule position, the host dropout step and the device dropout epoch all
     come from the state.  A state saved for another trainable set with the same element count is refused."""
     import parity_utils as pu
     from oracle.weights import synthetic_batch

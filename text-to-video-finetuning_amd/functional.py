@@ -1328,18 +1328,24 @@ def lora_group_drop_ok(x, group, scale):
     M, K = x.shape[0], group.cin_p
     if M < _LORA_EPI_MIN_ROWS:
         return False
-    key = (M, K, group.npad, group.npad_each, group.rp, group.rp_each, group.rk, _ld(group.down_t16))
+    # (the descriptors are probed with the leading dimensions the launches use — the input's own row stride forward;
+    #  backward the gradient arrives as column blocks of one [M, npad] buffer or is concatenated into one, `_LoraGroupDrop.backward`)
+    ldx = _ld(x)
+    key = (M, K, group.npad, group.npad_each, group.rp, group.rp_each, group.rk, _ld(group.down_t16), ldx)
     hit = _group_ok_cache.get(key)
     if hit is None:
         p16 = 16                                    # (aligned dummy addresses: t2v_gemm_lr_ok reads the descriptor only)
-        fwd = dict(M=M, N=group.npad, K=K, A=p16, lda=K, B=p16, ldb=K, D=p16, ldd=group.npad, B2=p16, ldb2=K, D2=p16, ldd2=group.rp,
+        fwd = dict(M=M, N=group.npad, K=K, A=p16, lda=ldx, B=p16, ldb=K, D=p16, ldd=group.npad, B2=p16, ldb2=K, D2=p16, ldd2=group.rp,
                    lr=dict(mode=2, rp=group.rp_each, b=p16, ldb=group.rk, scale=float(scale), drop_p=0.1, drop_seed=1,
                            group_cols=group.npad_each, group_seeds=(2, 3)[: max(0, group.n - 1)]))
         bwd = dict(M=M, N=K, K=group.npad, A=p16, lda=group.npad, B=p16, ldb=group.npad, D=p16, ldd=K,
                    lr=dict(mode=1, rp=group.rp, taps=1, a=p16, lda=group.rp, b=p16, ldb=_ld(group.down_t16)))
         try:
             hit = _lr_ok(fwd) and _lr_ok(bwd)
-        except Exception:   # noqa: BLE001  (a descriptor make_gemm itself refuses)
+        except Exception as e:   # noqa: BLE001  (a descriptor make_gemm itself refuses)
+            import warnings
+            warnings.warn(f"t2v_amd: the grouped dropped-LoRA form was refused for M={M} K={K} N={group.npad} ({type(e).__name__}: {e}); "
+                          f"these projections run member by member")
             hit = False
         _group_ok_cache[key] = hit
     return hit
