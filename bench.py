@@ -527,9 +527,9 @@ def temporal_fused_forward(unet, frames, H, W, dev):
 
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel family in the step AS IT RUNS (every tile the shipped table selects),
-    from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r05_pmc_step.json, else round 4's: rocprofv3 --pmc
+    from the committed whole-step counter passes (scripts/pmc_step.sh -> profiles/r06_pmc_step.json, else an earlier round.s: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE, separate passes; PMC collection is slow and never part of the timed bench)."""
-    for name in ("r05_pmc_step.json", "r04_pmc_step.json"):      # the newest committed counter passes
+    for name in ("r06_pmc_step.json", "r05_pmc_step.json", "r04_pmc_step.json"):      # the newest committed counter passes
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)

@@ -16,7 +16,7 @@ FAMILIES = [("gemm_kernel_dma", GEMM_LABEL), ("gemm_w8_kernel", GEMM_LABEL), ("g
             ("lora_prep", "lora_prep_kernel"),
             ("gemm_kernel<", "gemm_kernel<..,AT|BT> (K-major operands)"), ("gemm_pair", "gemm_pair_kernel"),
             ("gemm_finalize", "gemm_finalize_kernel (split-K)"), ("lora_wgrad", "lora_wgrad_kernel (factor gradients)"),
-            ("lora_merge", "lora_merge_kernel"), ("gn_stats_kernelILb0", "gn_stats (forward)"), ("gn_stats_kernelILb1", "gn_stats (backward)"),
+            ("lora_merge", "lora_merge_kernel"), ("temporal_fused", "temporal_fused_fwd_kernel"), ("gn_stats_kernelILb0", "gn_stats (forward)"), ("gn_stats_kernelILb1", "gn_stats (backward)"),
             ("gn_apply_kernelILb0", "gn_apply (forward)"), ("gn_apply_kernelILb1", "gn_apply (backward)"),
             ("ln_fwd", "ln_fwd"), ("ln_bwd", "ln_bwd"), ("attn_fwd_packed", "attn_fwd_packed (temporal)"),
             ("attn_bwd_packed", "attn_bwd_packed (temporal)"), ("attn_fwd_wg", "attn_fwd_wg (spatial, shared K/V tiles)"),
@@ -75,9 +75,11 @@ def main():
                            hbm_GB_per_step=round((read_b + write_b) / execs / 1e9, 2),
                            GBps_while_running=round((read_b + write_b) / d["us"] / 1e3, 1))
     out = dict(what="rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes, scripts/pmc_step.sh) over "
-                    "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-default-mode --no-host-timing` (config C2 in the reference's "
-                    f"default train mode, shipped tile table, HIP-graph replay): the last {execs} steps of the trace (the timed replays); "
-                    "per-kernel-family totals",
+                    "`python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-default-mode --no-host-timing` (config C2 in the "
+                    f"reference's default train mode, shipped tile table, EAGER step — the counter tool serialises dispatches and crashed under a "
+                    f"captured CLIP tower, scripts/pmc_step.sh; same kernels on the same tiles as the replayed graph): the last {execs} steps of the "
+                    "trace (the timed steps); per-kernel-family totals",
+               note="counters sit at the eight XCD L2s' memory side: operands shared by workgroups on different XCDs are counted once per XCD",
                fetch_correction="reads = 2 x FETCH_SIZE: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16 B/lane streaming "
                                 "read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both in KB",
                families=rows)

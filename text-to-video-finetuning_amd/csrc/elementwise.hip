@@ -418,6 +418,31 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
   if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
 }
 
+// Round 6: the same loss from ONE workgroup (16 waves, fixed summation order): the reported loss of a step is bit-reproducible.
+// The multi-workgroup form above adds its partial sums with float atomics in arrival order — the loss differed in its last bits
+// from run to run (profiles/r06_determinism.txt) although the gradient `dpred` never depended on the sum.  A prediction of the
+// benchmark clip is 131 072 elements (128 per lane); launches above 4 M elements keep the multi-workgroup form.
+__global__ __launch_bounds__(1024) void mse_kernel_one(const float* __restrict__ pred, const float* __restrict__ target, long long n,
+                                                        float* __restrict__ loss, float* __restrict__ dpred, float gscale) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const float inv = 1.f / (float)n;
+  for (long long i = threadIdx.x; i < n; i += 1024) {
+    float d = pred[i] - target[i];
+    acc += d * d;
+    if (dpred) dpred[i] = 2.f * d * inv * gscale;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    *loss += t * inv;                               // (the caller accumulates the two passes of a step into one scalar)
+  }
+}
+
 // Two fixed-order stages (no floating-point atomics): every data-parallel replica must derive the SAME clip coefficient from
 // the same reduced gradient, bit for bit — an atomic sum differs in its last bits between ranks and lets the replicas drift.
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ partial) {
@@ -715,8 +740,11 @@ extern "C" int t2v_smallconv(const T2VSmallConv* p, t2v_stream_t s) {
 extern "C" int t2v_mse_fwd_bwd(const float* pred, const float* target, long long n, float* loss, float* dpred, float gscale,
                                t2v_stream_t s) {
   T2V_CHECK_ARG(pred && target && loss && n > 0, "t2v_mse_fwd_bwd: bad args");
-  hipLaunchKernelGGL(mse_kernel, dim3((int)max(1LL, min((n + 255) / 256, 1024LL))), dim3(256), 0, (hipStream_t)s, pred, target,
-                     n, loss, dpred, gscale);
+  if (n <= (4LL << 20))
+    hipLaunchKernelGGL(mse_kernel_one, dim3(1), dim3(1024), 0, (hipStream_t)s, pred, target, n, loss, dpred, gscale);
+  else
+    hipLaunchKernelGGL(mse_kernel, dim3((int)max(1LL, min((n + 255) / 256, 1024LL))), dim3(256), 0, (hipStream_t)s, pred, target,
+                       n, loss, dpred, gscale);
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }

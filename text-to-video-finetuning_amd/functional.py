@@ -95,10 +95,16 @@ def note_weights_changed():
 
 
 def clear_weight_cache(model=None):
-    """Drop cached prepared copies (they live on the Parameter objects themselves, so they die with the model)."""
+    """Drop cached prepared copies (they live on the Parameter objects themselves, so they die with the model) and the folded
+    LoRA weights of the no-grad forward (models/leaves.py: `W + s up down` per wrapper and the fused temporal units' [3C, C] /
+    permuted Wo copies, cached on the modules — ~2 bytes per UNet weight after a sampling pass with wrappers in place)."""
     if model is not None:
         for p in model.parameters():
             p.__dict__.pop("_t2v_prep", None)
+        for m in model.modules():
+            m.__dict__.pop("_t2v_folded", None)
+            m.__dict__.pop("_t2v_fused_w", None)
+            m.__dict__.pop("_t2v_nograd_w", None)
 
 
 def _prep_compute(w, kind, cfg):

@@ -351,8 +351,37 @@ class Attention(nn.Module):
                 return None
         return g
 
+    def _no_grad_group(self, mods):
+        """One frozen bf16 Parameter [sum N_i, K] = the rows of the members' effective weights (W, or W + s up down of a wrapper
+        with inactive dropout), for a forward-only call: to_q | to_k | to_v (or to_k | to_v over the text states) as ONE launch —
+        the grouped projections of the training forward (lora_bank.py) need a trainer; sampling has none.  None: a member has a
+        bias or a flavour `_effective_weight` does not express."""
+        parts = [_effective_weight(m) for m in mods]
+        if any(p is None or p[2] is not None for p in parts):
+            return None
+        tag = tuple(p[0] for p in parts)
+        hit = self.__dict__.get("_t2v_nograd_w", {}).get(len(mods))
+        if hit is None or hit[0] != tag:
+            ws = [p[1]() for p in parts]
+            hit = (tag, nn.Parameter(torch.cat(ws, dim=0).contiguous(), requires_grad=False), [w.shape[0] for w in ws])
+            self.__dict__.setdefault("_t2v_nograd_w", {})[len(mods)] = hit
+        return hit
+
     def forward(self, x, qlay, ctx=None, klay=None, residual=None):
         src = x if ctx is None else ctx
+        if not torch.is_grad_enabled() and _fold_no_grad:
+            mods = (self.to_q, self.to_k, self.to_v) if ctx is None else (self.to_k, self.to_v)
+            hit = self._no_grad_group(mods)
+            if hit is not None and hit[1].device == src.device and hit[1].shape[1] == src.shape[1]:
+                y = F.conv_linear(src, hit[1], None)
+                cols, off = [], 0
+                for n_ in hit[2]:
+                    cols.append(y[:, off:off + n_])
+                    off += n_
+                q = cols[0] if ctx is None else run_layer(self.to_q, x)
+                k, v = cols[-2], cols[-1]
+                o = F.attention(q, k, v, self.heads, qlay, qlay if klay is None else klay, self.scale)
+                return run_layer(self.to_out[0], o, residual=residual)
         g = self._fused_group(ctx is None)
         if g is not None:
             p0 = _drop_p(getattr(g.mods[0], "dropout", None))
