@@ -545,13 +545,14 @@ def pmc_traffic():
 
 def rocprof_family_time(algorithmic_flops):
     """The same family's kernel time in the steady-state GRAPH REPLAY of this bench, from the committed rocprofv3 kernel trace
-    (scripts/profile_bench.sh -> profiles/r05_bench_c2_kernel_stats.txt; pure kernel durations, no per-launch dispatch gap).
+    (scripts/profile_bench.sh -> profiles/r06_bench_c2_kernel_stats.txt; pure kernel durations, no per-launch dispatch gap).
     The live event pairs of the eager instrumented pass above also contain each launch's dispatch latency (~5 us x 955), which a
     graph replay overlaps with the previous kernel; both numbers are reported."""
     try:
         ms = 0.0
         n = 0
-        src = "r05_bench_c2_kernel_stats.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r05_bench_c2_kernel_stats.txt")) else "r04_bench_c2_kernel_stats.txt"
+        src = next(f for f in ("r06_bench_c2_kernel_stats.txt", "r05_bench_c2_kernel_stats.txt", "r04_bench_c2_kernel_stats.txt")
+                   if os.path.exists(os.path.join(ROOT, "profiles", f)))      # the newest committed trace
         with open(os.path.join(ROOT, "profiles", src)) as f:
             for line in f:
                 if ("gemm_kernel_dma" in line or "gemm_w8_kernel" in line or "gemm_skinny_kernel" in line) and line.lstrip().startswith("_Z"):
