@@ -17,14 +17,21 @@
 //     (lane = head dim, registers = row slots): S^T = k q^T then needs no data movement at all — the accumulators of k^T / q^T
 //     ARE the A / B operands (the head-dim permutation the accumulator layout imposes is the same on both sides), the softmax
 //     runs over registers + one exchange between the half-waves, P^T is the B operand and v the A operand of O^T = v^T P^T,
-//   * O^T (lane = row slot, registers = head dims) is the A operand of the output projection; the permutation of its head dims
-//     is undone by reading the Wo fragment as two 8-byte halves instead of one 16-byte chunk.
+//   * O^T (lane = row slot, registers = head dims) is an operand of the output projection as it stands; the permutation of its
+//     head dims is undone on the HOST: Wo arrives with its input index permuted inside every group of 16 (t2v_abi.h), so that
+//     the matching Wo fragment is one 16-byte LDS read.  The projection is computed transposed (out^T = Wo O^T: lane = row
+//     slot) and leaves through a per-wave fp32 staging tile as row-contiguous 16-byte stores, bias and residual added in fp32.
 // Only WEIGHTS go through LDS: [192 x 64] chunks (q | k | v rows of one head, 64 input channels) and then [NBO*32 x 64] chunks of
 // Wo stream through a four-stage ring by LDS-DMA (buffer_load ... lds, 16 B per lane, lane-linear image with the XOR swizzle
 // of csrc/gemm.hip), counted s_waitcnt vmcnt + one s_barrier per chunk.  One workgroup per CU (up to ~460 registers per lane).
 //
 // Rooflines: MFMA-bound, 8 C^2 + 4 F C flops per row against 2.5 PFLOP/s; every workgroup reads all 4 C^2 weights once from
-// its XCD's L2 (3.3 MB at C = 640) and its rows of x twice.
+// its XCD's L2 (3.3 MB at C = 640) and its rows of x twice.  Measured: 0.22 - 0.24 of the peak at C = 320 / 512 (DESIGN.md 2.4 has
+// the break-down by ablation: T2VTemporalFused.ablate).
+//
+// NOTE on the hand-issued LDS reads below: a fragment register is written by an inline-asm ds_read and becomes valid at the
+// explicit s_waitcnt of tf_lds_wait — the compiler must not copy or spill it in between.  Every instantiation is checked
+// against an fp32 reference by tests/test_kernels_gpu.py::test_temporal_unit_fused_forward; re-run it after ANY edit here.
 #include "common.h"
 
 namespace {
