@@ -249,6 +249,49 @@ def test_graph_replay_equals_eager(mode, monkeypatch):
     t2.check_device_flags()          # no in-launch split-K reduction gave up (the 0xdead word is read by the host)
 
 
+def test_validation_sampling_between_replayed_train_steps_sees_the_current_weights():
+    """train.py:895-958 in this library's terms: a trainer replays captured train steps (parameters move under t2v_adamw inside
+    the graphs: no torch version counter changes), validation samples with the SAME UNet in eval mode through the sampler's own
+    captured UNet call, training goes on, validation samples again.  Each sampling pass must equal the eager sampler on the
+    weights of that moment (folded LoRA weights, fused temporal weights and the capture all follow functional.weights_epoch), the
+    second pass must differ from the first (the weights did move), and the train steps after a sampling pass must go on as before."""
+    from oracle.weights import synthetic_batch
+    from t2v_amd.pipelines import TextToVideoSampler
+    from t2v_amd.schedulers import DPMSolverMultistepScheduler
+    from t2v_amd.training import DenoiseTrainer
+    _, _, dunet, dvae, _ = _build(r=4, lora_up_scale=0.3)
+    params = [p for p in dunet.parameters() if p.requires_grad]
+    batch = {k: v.cuda() for k, v in synthetic_batch(4, 64, 64, seed=7, text_dim=64).items()}
+    tr = DenoiseTrainer(dunet, dvae, params, lr=2e-2)            # (large steps: the second validation must visibly differ)
+    tr.capture(batch, warmup=1)
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, 4, 4, 8, 8, generator=g).cuda()
+    pos, neg = torch.randn(1, 77, 64, generator=g).cuda(), torch.randn(1, 77, 64, generator=g).cuda()
+    kw = dict(num_inference_steps=3, guidance_scale=4.0)
+    replayed = TextToVideoSampler(dunet, DPMSolverMultistepScheduler(), graph=True)
+    eager = TextToVideoSampler(dunet, DPMSolverMultistepScheduler(), graph=False)
+
+    def validate():
+        dunet.eval()
+        try:
+            a = replayed(pos, neg, latents=lat.clone(), **kw)
+            b = eager(pos, neg, latents=lat.clone(), **kw)
+        finally:
+            dunet.train()
+        assert bool(torch.isfinite(a).all())
+        assert relerr(a, b) < 1e-6, relerr(a, b)
+        return a
+
+    losses = [float(tr.replay_step(batch)) for _ in range(2)]
+    v1 = validate()
+    losses += [float(tr.replay_step(batch)) for _ in range(3)]
+    v2 = validate()
+    torch.cuda.synchronize()
+    assert relerr(v2, v1) > 1e-3, "three optimiser steps at lr 2e-2 must move the samples"
+    assert all(l == l and l < 10 for l in losses) and losses[-1] < losses[0], losses     # training went on (same batch: the loss falls)
+    tr.check_device_flags()
+
+
 @pytest.mark.parametrize("host_batches", [False, True])
 def test_pipelined_replays_without_host_sync_follow_the_eager_trajectory(host_batches):
     """The pipelined capture form with the host running ahead: six replays on six DIFFERENT batches, no synchronisation in
