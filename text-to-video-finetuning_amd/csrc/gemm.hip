@@ -751,10 +751,28 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
   // three register sets: the global loads of K step i+3 are issued while step i computes (the operands of the weight-gradient
   // launches stream from HBM exactly once: with ONE step of prefetch every K step paid a full memory round trip, 3.6 us per
   // 64-deep step at config C3 — profiles/r03_c3_kernel_stats.txt)
-  bf16x8 rA[3][NCA], rB[3][NCB];
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // (the sets are 4 x u32 vectors: as asm operands of type short8 the compiler re-packed them element-wise — v_lshrrev / v_perm on
+  //  registers whose loads were still in flight, found in the 64x64 instantiation)
+  typedef __attribute__((ext_vector_type(4))) unsigned kreg_t;
+  kreg_t rA[3][NCA], rB[3][NCB];
 
-  auto load_tiles = [&](int k0, bf16x8(&ra)[NCA], bf16x8(&rb)[NCB]) {
+  // Round 6, what the ISA of the weight-gradient launches showed (config C3: 575 launches, 40 ms, 0.093 of the MFMA peak; 63 % of
+  // the wave cycles parked, scripts/kmajor_shape_run.py under the counter passes):
+  //  (1) with the load inside the three-way branch on the (kernel-uniform) operand mode the compiler emitted one global_load per
+  //      branch and an `s_waitcnt vmcnt(0)` at every merge: the loads of a step went out one at a time, each behind the previous
+  //      one's round trip.  Addresses are formed first, the loads follow back to back (invalid chunks read the zero page instead
+  //      of being predicated: no exec-mask branches either).
+  //  (2) the three register sets bought nothing: the wait in front of the LDS store was vmcnt(0), i.e. it also waited for the loads
+  //      issued a moment earlier for step i + 3 — every merge of the `if (i + 3 < nt)` / `if (i + 1 < nt)` conditionals inside
+  //      the unrolled body makes the wait-count analysis conservative.  The steady state below is branch-free (see the main loop).
+  //  (Hand-issued asm loads with counted waits were tried and REJECTED: the register sets are loop-carried, and the compiler
+  //   copies / re-packs loop-carried values at the loop entry — i.e. while their loads are still in flight; wrong results in
+  //   the 64x64 instantiation.)
+  const bf16_t* zpage = (const bf16_t*)g_zero_page;
+  auto ld16 = [](kreg_t& r, const bf16_t* ptr) { r = *(const kreg_t*)ptr; };
+  auto load_tiles = [&](int k0, kreg_t(&ra)[NCA], kreg_t(&rb)[NCB]) {
+    const bf16_t* pa[NCA];
+    const bf16_t* pb[NCB];
     if constexpr (!AT) {
       const int kidx = k0 + (tid & 7) * 8;
       const bool kok = kidx < kend;
@@ -766,11 +784,11 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
           bool v;
           long long sr = src_row(posA[i], tap, g, v);
           v = v && kok;
-          ra[i] = v ? *(const bf16x8*)(A + sr * p.lda + c) : zero8;
+          pa[i] = v ? A + sr * p.lda + c : zpage;
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < NCA; ++i) ra[i] = (aok[i] && kok) ? *(const bf16x8*)(arow[i] + kidx) : zero8;
+        for (int i = 0; i < NCA; ++i) pa[i] = (aok[i] && kok) ? arow[i] + kidx : zpage;
       }
     } else {
       constexpr int CPR = BM / 8, RPP = 256 / CPR;
@@ -779,7 +797,7 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
       for (int i = 0; i < NCA; ++i) {
         int kk = k0 + tid / CPR + RPP * i;
         bool v = (kk < kend) && (mm < M);
-        ra[i] = v ? *(const bf16x8*)(A + (long long)kk * p.lda + mm) : zero8;
+        pa[i] = v ? A + (long long)kk * p.lda + mm : zpage;
       }
     }
     if constexpr (!BT) {
@@ -787,8 +805,7 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
       const bool kok = kidx < kend;
       const bool win = kidx >= wlo && kidx < whi;
 #pragma unroll
-      for (int i = 0; i < NCB; ++i)
-        rb[i] = (bok[i] && kok && (win || !((b2mask >> i) & 1u))) ? *(const bf16x8*)(brow[i] + kidx) : zero8;
+      for (int i = 0; i < NCB; ++i) pb[i] = (bok[i] && kok && (win || !((b2mask >> i) & 1u))) ? brow[i] + kidx : zpage;
     } else {
       constexpr int CPR = BN / 8, RPP = 256 / CPR;
       const int nn = n0 + (tid % CPR) * 8;
@@ -796,51 +813,56 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
       for (int i = 0; i < NCB; ++i) {
         int kk = k0 + tid / CPR + RPP * i;
         bool v = (kk < kend) && (nn < N);
+        const bf16_t* src;
         if (p.b_conv) {
           Pos ps = decompose(kk, kend, g);
           bool v2;
           long long sr = src_row(ps, btap, g, v2);
           v = v && v2;
-          rb[i] = v ? *(const bf16x8*)(B + sr * p.ldb + bc) : zero8;
+          src = B + sr * p.ldb + bc;
         } else if (p.b_tapflip) {
           int tapi = kk / g.C, jr = kk - tapi * g.C;
-          rb[i] = v ? *(const bf16x8*)(B + (long long)jr * p.ldb + (long long)(g.KH * g.KW - 1 - tapi) * N + nn) : zero8;
+          src = B + (long long)jr * p.ldb + (long long)(g.KH * g.KW - 1 - tapi) * N + nn;
         } else {
-          rb[i] = v ? *(const bf16x8*)(B + (long long)kk * p.ldb + nn) : zero8;
+          src = B + (long long)kk * p.ldb + nn;
         }
+        pb[i] = v ? src : zpage;
       }
     }
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) ld16(ra[i], pa[i]);
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) ld16(rb[i], pb[i]);
   };
-
-  auto store_tiles = [&](int stage, const bf16x8(&ra)[NCA], const bf16x8(&rb)[NCB]) {
+  auto store_tiles = [&](int stage, const kreg_t(&ra)[NCA], const kreg_t(&rb)[NCB]) {
     unsigned char* sA = smem + stage * STAGE;
     unsigned char* sB = sA + A_BYTES;
     if constexpr (!AT) {
 #pragma unroll
       for (int i = 0; i < NCA; ++i) {
         int row = (tid >> 3) + 32 * i;
-        *(bf16x8*)(sA + row * 128 + ((((tid & 7) ^ ((row >> 1) & 7))) << 4)) = ra[i];
+        *(kreg_t*)(sA + row * 128 + ((((tid & 7) ^ ((row >> 1) & 7))) << 4)) = ra[i];
       }
     } else {
       constexpr int CPR = BM / 8, RPP = 256 / CPR;
 #pragma unroll
       for (int i = 0; i < NCA; ++i) {
         int kr = tid / CPR + RPP * i;
-        *(bf16x8*)(sA + (kr * LDA_T + (tid % CPR) * 8) * 2) = ra[i];
+        *(kreg_t*)(sA + (kr * LDA_T + (tid % CPR) * 8) * 2) = ra[i];
       }
     }
     if constexpr (!BT) {
 #pragma unroll
       for (int i = 0; i < NCB; ++i) {
         int row = (tid >> 3) + 32 * i;
-        *(bf16x8*)(sB + row * 128 + ((((tid & 7) ^ ((row >> 1) & 7))) << 4)) = rb[i];
+        *(kreg_t*)(sB + row * 128 + ((((tid & 7) ^ ((row >> 1) & 7))) << 4)) = rb[i];
       }
     } else {
       constexpr int CPR = BN / 8, RPP = 256 / CPR;
 #pragma unroll
       for (int i = 0; i < NCB; ++i) {
         int kr = tid / CPR + RPP * i;
-        *(bf16x8*)(sB + (kr * LDB_T + (tid % CPR) * 8) * 2) = rb[i];
+        *(kreg_t*)(sB + (kr * LDB_T + (tid % CPR) * 8) * 2) = rb[i];
       }
     }
   };
@@ -903,9 +925,22 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
   if (nt > 2) load_tiles(kbeg + 2 * BK, rA[2], rB[2]);
   store_tiles(0, rA[0], rB[0]);
   __syncthreads();
-  for (int it = 0; it < nt; it += 3) {
+  int it = 0;
+  // steady state: K steps it, it+1, it+2 with NO conditional inside — step i sits in register set i % 3 (until stored) and LDS
+  // stage i & 1; every sub-step requests step i + 3, multiplies step i and stores step i + 1
+  for (; it + 5 < nt; it += 3) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {                    // K step i = it + u sits in register set u (until stored) and LDS stage i & 1
+    for (int u = 0; u < 3; ++u) {
+      const int i = it + u, cur = i & 1;
+      load_tiles(kbeg + (i + 3) * BK, rA[u], rB[u]);
+      compute(cur);
+      store_tiles(cur ^ 1, rA[(u + 1) % 3], rB[(u + 1) % 3]);
+      __syncthreads();
+    }
+  }
+  for (; it < nt; it += 3) {                         // the last (up to five) steps
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
       const int i = it + u;
       if (i < nt) {
         const int cur = i & 1;
@@ -920,8 +955,10 @@ __device__ __forceinline__ void gemm_body(const T2VGemm& p, unsigned char* smem,
   epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, z, zoffD, zoffR);
 }
 
+// (two workgroups per CU: the branch-free steady-state copy of the K loop would otherwise take the 128x128 instantiation past 256
+//  registers — one wave per SIMD, and the launches with many tiles lost more than the precise waits won)
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
-__global__ __launch_bounds__(256) void gemm_kernel(const T2VGemm p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const T2VGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   warm_kernargs<(int)sizeof(T2VGemm)>();
   gemm_body<BM, BN, WM, WN, AT, BT>(p, smem, blockIdx.x, gridDim.x, blockIdx.z);

@@ -58,12 +58,16 @@ __device__ __forceinline__ bf16x8 tf_pack8(const f32x16& a, int r0) {
 // Fragment reads are hand-issued (ds_read_b128 through inline asm, explicit s_waitcnt lgkmcnt): the compiler's scheduler sinks
 // every LDS read to just in front of the MFMA that consumes it (read -> wait -> multiply, one at a time: measured 0.11 of peak),
 // and with one wave per SIMD nothing else hides that latency.  Here the reads of k-step i+1 are issued, then the MFMAs of k-step i.
+// (fragment registers are 4 x u32 vectors while they are asm operands: as short8 operands the compiler may re-pack them element by
+//  element — v_lshrrev / v_perm on a register whose read is still in flight; seen in csrc/gemm.hip's K-major loads, round 6)
+typedef __attribute__((ext_vector_type(4))) unsigned tfreg_t;
+__device__ __forceinline__ bf16x8 tf_bf(const tfreg_t& w) { return __builtin_bit_cast(bf16x8, w); }
 template <int OFF>
-__device__ __forceinline__ void tf_lds_read(bf16x8& w, unsigned addr) {
+__device__ __forceinline__ void tf_lds_read(tfreg_t& w, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(addr), "n"(OFF));
 }
 template <int N>
-__device__ __forceinline__ void tf_lds_read_n(bf16x8 (&w)[N], unsigned addr) {
+__device__ __forceinline__ void tf_lds_read_n(tfreg_t (&w)[N], unsigned addr) {
   tf_lds_read<0>(w[0], addr);
   if constexpr (N > 1) tf_lds_read<4096>(w[1], addr);
   if constexpr (N > 2) tf_lds_read<8192>(w[2], addr);
@@ -72,7 +76,7 @@ __device__ __forceinline__ void tf_lds_read_n(bf16x8 (&w)[N], unsigned addr) {
   if constexpr (N > 5) tf_lds_read<20480>(w[5], addr);
 }
 template <int N>
-__device__ __forceinline__ void tf_lds_wait(bf16x8 (&w)[N]) {
+__device__ __forceinline__ void tf_lds_wait(tfreg_t (&w)[N]) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int j = 0; j < N; ++j) asm volatile("" : "+v"(w[j]));      // the fragments are defined from here on
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) of[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   const float sc = p.scale;
-  bf16x8 wc[6], wn[6];                                              // fragments of the k-step being multiplied / of the next one
+  tfreg_t wc[6], wn[6];                                              // fragments of the k-step being multiplied / of the next one
   tf_lds_read_n<6>(wc, frag_addr(0, 0));
   tf_lds_wait<6>(wc);
   for (int h = 0; h < H; ++h) {
@@ -238,11 +242,11 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 a = nf[kc * 4 + kk];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) aq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[j], a, aq[j], 0, 0, 0);          // q^T[d][row]
+        for (int j = 0; j < 2; ++j) aq[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf_bf(wc[j]), a, aq[j], 0, 0, 0);          // q^T[d][row]
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ak[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 + j], a, ak[j], 0, 0, 0);      // k^T[d][row]
+        for (int j = 0; j < 2; ++j) ak[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf_bf(wc[2 + j]), a, ak[j], 0, 0, 0);      // k^T[d][row]
 #pragma unroll
-        for (int j = 0; j < 2; ++j) av[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wc[4 + j], av[j], 0, 0, 0);      // v[row][d]
+        for (int j = 0; j < 2; ++j) av[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tf_bf(wc[4 + j]), av[j], 0, 0, 0);      // v[row][d]
         __builtin_amdgcn_sched_barrier(0);
         if (more) tf_lds_wait<6>(wn);
 #pragma unroll
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
   int orow[2];                                                      // rows this lane stores in the output pass: slots lane/4 and lane/4 + 16
 #pragma unroll
   for (int i = 0; i < 2; ++i) orow[i] = __shfl(arow, (lane >> 2) + 16 * i);
-  bf16x8 vc[NBO], vn[NBO];
+  tfreg_t vc[NBO], vn[NBO];
   tf_lds_read_n<NBO>(vc, frag_addr(NA, 0));
   tf_lds_wait<NBO>(vc);
   for (int nb = 0; nb < NOUT; ++nb) {
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(TF_NT) void temporal_fused_fwd_kernel(const T2VTemp
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 a = of[kc * 4 + kk];
 #pragma unroll
-        for (int j = 0; j < NBO; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[j], a, acc[j], 0, 0, 0);
+        for (int j = 0; j < NBO; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf_bf(vc[j]), a, acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) tf_lds_wait<NBO>(vn);
 #pragma unroll

@@ -346,10 +346,16 @@ def raise_on_gemm_flags(pending):
                            "step are wrong (restore the last checkpoint); the arrival counters have been re-armed")
 
 
+_KMAJOR_WGS = int(os.environ.get("T2V_KMAJOR_WGS", "800"))
+
+
 def _split_k(tiles, kdim):
-    """K splits of a K-major launch with `tiles` 64x64 output tiles: about 1600 workgroups (measured optimum of the weight-
-    gradient signatures at 320^2 .. 1280^2 outputs, scripts/kmajor_probe.py), at least 128 reduction rows per split."""
-    return int(max(1, min(64, 1600 // max(1, tiles), kdim // 128)))
+    """K splits of a K-major launch with `tiles` 64x64 output tiles: about `_KMAJOR_WGS` workgroups, at least 128 reduction rows per
+    split.  1600 was the optimum of round 3's K loop (scripts/kmajor_probe.py); with the round-6 loop (loads back to back, two
+    younger steps kept in flight) a workgroup streams faster and the fp32-atomic hand-over of every extra split costs more than
+    it buys: 800 is the measured optimum of the C3 step (profiles/r06_c3_split_policy.txt: 156.8 / 152.2 / 154.6 / 155.0 / 158.8 ms
+    at 1600 / 800 / 560 / 400 / 280)."""
+    return int(max(1, min(64, _KMAJOR_WGS // max(1, tiles), kdim // 128)))
 
 
 # --------------------------------------------------------------------------- Linear / Conv (implicit GEMM)
