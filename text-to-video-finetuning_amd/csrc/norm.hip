@@ -306,22 +306,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 // LN_MAXCH chunks of 8 per lane (C <= 512 * LN_MAXCH) and LN_RW rows per wave and trip are template parameters: the common
 // C = 320 rows need one chunk per lane and leave registers for eight rows in flight
 
+// what an out-of-range 16-byte chunk reads.  (Round 6, found in the ISA: the row loads of both LayerNorm kernels were predicated
+// `if (ch < nch && row < rows) x = load` — every load sat behind an exec-mask branch and the compiler put `s_waitcnt vmcnt(0)` at each
+// merge, so the "eight rows in flight per wave" went out ONE AT A TIME, each behind the previous row's round trip.  The loads are
+// unconditional now: an out-of-range chunk reads this page, and the statistics of the backward come from a clamped row.)
+__device__ __attribute__((aligned(16))) unsigned g_ln_zero_page[8];
+
 template <int LN_MAXCH, int LN_RW_F>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
                                                       long long ldy, int rows, int C, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* __restrict__ stats) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = C >> 3;
+  // the affine terms of this lane's channels, once per wave (round 6: inside the row loop they were re-loaded for every row —
+  // four loads and a full wait per row between the reduction and the store)
+  float gm[LN_MAXCH][8], bt[LN_MAXCH][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = min(lane + 64 * i, nch - 1);           // (scalar loads: a parameter inside the flat buffer is only 4-byte aligned)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gm[i][e] = gamma[ch * 8 + e];
+      bt[i][e] = beta[ch * 8 + e];
+    }
+  }
   // LN_RW_F rows per wave and trip: the 16-byte loads of all of them are issued before the first row is reduced (one row per
   // wave left a single load round trip in flight per wave — 2.2 TB/s at level 0)
   for (long long row0 = ((long long)blockIdx.x * 4 + wv) * LN_RW_F; row0 < rows; row0 += (long long)gridDim.x * 4 * LN_RW_F) {
     bf16x8 xq[LN_RW_F][LN_MAXCH];
+    const bf16_t* zpage = (const bf16_t*)g_ln_zero_page;
 #pragma unroll
     for (int r = 0; r < LN_RW_F; ++r)
 #pragma unroll
       for (int i = 0; i < LN_MAXCH; ++i) {
         const int ch = lane + 64 * i;
-        if (ch < nch && row0 + r < rows) xq[r][i] = *(const bf16x8*)(x + (row0 + r) * ldx + ch * 8);
+        const bf16_t* src = (ch < nch && row0 + r < rows) ? x + (row0 + r) * ldx + ch * 8 : zpage;
+        xq[r][i] = *(const bf16x8*)src;
       }
 #pragma unroll
     for (int r = 0; r < LN_RW_F; ++r) {
@@ -365,7 +385,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
         if (ch < nch) {
           bf16x8 ov;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf((v[i][e] - mu) * rs * gamma[ch * 8 + e] + beta[ch * 8 + e]);
+          for (int e = 0; e < 8; ++e) ov[e] = (short)f2bf((v[i][e] - mu) * rs * gm[i][e] + bt[i][e]);
           *(bf16x8*)(y + row * ldy + ch * 8) = ov;
         }
       }
@@ -392,21 +412,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   for (long long row0 = ((long long)blockIdx.x * 4 + wv) * LN_RW_B; row0 < rows; row0 += (long long)gridDim.x * 4 * LN_RW_B) {
     bf16x8 xq[LN_RW_B][LN_MAXCH], gq[LN_RW_B][LN_MAXCH], aq[LN_RW_B][LN_MAXCH];
     float mus[LN_RW_B], rss[LN_RW_B];
+    const bf16_t* zpage = (const bf16_t*)g_ln_zero_page;
 #pragma unroll
     for (int r = 0; r < LN_RW_B; ++r) {
       const long long row = row0 + r;
-      if (row < rows) {
-        mus[r] = stats[row * 2];
-        rss[r] = stats[row * 2 + 1];
+      const bool rok = row < rows;
+      const long long rc = rok ? row : rows - 1;           // (a clamped row: its values are never used)
+      mus[r] = stats[rc * 2];
+      rss[r] = stats[rc * 2 + 1];
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
-          const int ch = lane + 64 * i;
-          if (ch < nch) {
-            xq[r][i] = *(const bf16x8*)(x + row * ldx + ch * 8);
-            gq[r][i] = *(const bf16x8*)(dy + row * lddy + ch * 8);
-            if (addend) aq[r][i] = *(const bf16x8*)(addend + row * ldadd + ch * 8);
-          }
-        }
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        const bool ok = rok && ch < nch;
+        xq[r][i] = *(const bf16x8*)(ok ? x + row * ldx + ch * 8 : zpage);
+        gq[r][i] = *(const bf16x8*)(ok ? dy + row * lddy + ch * 8 : zpage);
+        if (addend) aq[r][i] = *(const bf16x8*)(ok ? addend + row * ldadd + ch * 8 : zpage);
       }
     }
 #pragma unroll
