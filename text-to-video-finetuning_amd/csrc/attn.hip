@@ -284,10 +284,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dkdv_kernel(const T2VAttn p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = qt + crow(r, hi);
-      const bool ok = (qr < Sq) && kok && (!p.causal || key <= qr);
-      const float L = ok ? lsep[qr] * 1.44269504088896341f : 0.f;
-      const float D = ok ? dlp[qr] : 0.f;
-      float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -L)) : 0.f;
+      // (round 6: clamped loads + a data select instead of `ok ? load : 0` / `ok ? exp2 : 0`, which the compiler turned into
+      //  exec-mask branches per score element — see attn_bwd_dkdv_wg2_kernel)
+      const bool ok = (qr < Sq) & kok & (!p.causal | (key <= qr));
+      const int qc = min(qr, Sq - 1);
+      const float L = lsep[qc] * 1.44269504088896341f;
+      const float D = dlp[qc];
+      float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -L));
+      pv = ok ? pv : 0.f;
       pr[r] = pv;
       s[r] = pv * (dp[r] - D) * p.scale;
     }
@@ -831,9 +835,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_wg2_kernel(const T2VAttn p)
       fetch_rows((t + 1) * WG_ROWS);
     }
     const int qt0 = t * WG_ROWS;
-    const bool ragged = qt0 + WG_ROWS > Sq;
     auto block = [&](auto QB) {
       constexpr int qb = decltype(QB)::value, Q0 = 32 * qb * LDT;
+      const int qlim = Sq - qt0 - 32 * qb;                   // rows of this 32-query block that exist (>= 32 except in the last tile)
       bf16x8 qa[4], da[4], tq[2][2], td[2][2];
       lds_row_frags_c<Q0>(qa, rb);
       lds_row_frags_c<VOFF + Q0>(da, rb);
@@ -865,7 +869,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_wg2_kernel(const T2VAttn p)
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * g4 + i;
             float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lv[i]));
-            if (!kok[j] || (ragged && qt0 + 32 * qb + crow(r, hi) >= Sq)) pv = 0.f;
+            // (round 6: a data select, no short-circuit — `!kok[j] || (ragged && ...)` was compiled into an exec-mask branch PER
+            //  ELEMENT with the exponential sunk into it: ~12 scalar instructions per score element, 879 k SALU against 1 311 k VALU
+            //  instructions per SIMD in the counter passes of profiles/r06_attention_counters.txt)
+            const bool live = kok[j] & (crow(r, hi) < qlim);
+            pv = live ? pv : 0.f;
             pr[r] = pv;
             s[r] = pv * (dp[r] - dv[i]) * p.scale;
           }
@@ -1020,7 +1028,9 @@ __global__ __launch_bounds__(64) void attn_bwd_packed_kernel(const T2VAttn p, in
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pv = (R.ok && crow(r, hi) / S == R.sub) ? __expf(s[r] * p.scale - lse) : 0.f;
+      const bool live = R.ok & (crow(r, hi) / S == R.sub);
+      const float e = __expf(s[r] * p.scale - lse);
+      const float pv = live ? e : 0.f;
       s[r] = pv * (dp[r] - dl) * p.scale;
     }
     f32x16 a0, a1;
@@ -1047,8 +1057,9 @@ __global__ __launch_bounds__(64) void attn_bwd_packed_kernel(const T2VAttn p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = crow(r, hi);
-      const bool ok = R.ok && rr / S == R.sub;
-      const float pv = ok ? __expf(s[r] * p.scale - sL[rr]) : 0.f;
+      const bool ok = R.ok & (rr / S == R.sub);
+      const float e = __expf(s[r] * p.scale - sL[rr]);
+      const float pv = ok ? e : 0.f;
       pr[r] = pv;
       s[r] = pv * (dp[r] - sDl[rr]) * p.scale;
     }
