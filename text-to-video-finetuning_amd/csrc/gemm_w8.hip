@@ -44,6 +44,9 @@
 
 namespace {
 
+// 64 zero bytes: the target of epilogue operand loads whose operand is absent (the loads themselves are unconditional)
+__device__ __attribute__((aligned(64))) unsigned g_w8_zero[16];   // (not const: a constant-address-space object makes the selected pointer flat)
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -783,8 +786,22 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   // One fragment's operands at a time (the compiler hoists the column fragments' loads of a tap into one batch: ~2 us per tap).
   // Measured alternatives (scripts/lr_probe.py): both operands of two taps buffered in registers — spills, slower; both operands
   // staged in LDS by all 512 threads — three barriers and index arithmetic cost more than the round trips they save.
-  auto rank_phase = [&](int ib0_, auto nb_tag) {
+  // barrier of an LDS hand-over: waits for this wave's LDS operations only.  __syncthreads() also drains vmcnt, i.e. every
+  // epilogue operand requested ahead of its use (residual rows, LB rows) would be waited for at the next hand-over
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // `early`: called once, right after the phase's own operand loads have been issued — the register epilogue requests the
+  // residual rows of its first chunks there.  vmcnt retires in order: a load that is younger than those requests cannot be waited
+  // for without waiting for them, so on the K-group tiles (LBALL) the LB rows of ALL fragments go out first, at the top of the
+  // phase; the other kernels read them one fragment ahead (no early requests there), the staged ones — whose whole tile is live
+  // in registers during the phase — fragment by fragment.
+  auto rank_phase = [&](int ib0_, auto nb_tag, auto&& early) {
     constexpr int NB = decltype(nb_tag)::value;
+    constexpr bool LBALL = !CS && KG == 2;
+    constexpr int NLB = LBALL ? FN : (CS ? 1 : 2);
     const int half = lane >> 5, l31 = lane & 31;
     const int rp = p.lr_rp, nk = (rp + 15) >> 4, rkp = nk * 16;        // (nk <= 2 in mode 2, <= 3 in mode 1: launch_w8)
     const bool masked = p.lr_drop_p > 0.f;
@@ -810,7 +827,28 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       const int nkc = (rp + 15) >> 4;
       const float inv = p.lr_drop_p > 0.f ? 1.f / (1.f - p.lr_drop_p) : 1.f;
       bf16x8* xt = (bf16x8*)smem;                    // [WM * FM bands][4 chunks][64 lanes]
-      if (KG == 2) __syncthreads();                  // (the K-group exchange's reads of this LDS are over)
+      // LB rows: unconditional loads (columns beyond the base columns read the last one — never stored; a chunk beyond the rank
+      // re-reads chunk 0 — never multiplied)
+      auto load_lb3 = [&](int j, bf16x8(&lb)[4]) {
+        const int cl = min(col0_of(j) + l31, nbase - 1);
+        const bf16_t* lbp = LB + (unsigned)(n0 + cl) * (unsigned)p.lr_ldb + 4 * half;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int o = c < nkc ? 16 * c : 0;
+          const bf16x4 lo = *(const bf16x4*)(lbp + o);
+          const bf16x4 hi = *(const bf16x4*)(lbp + o + 8);
+          lb[c] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      };
+      bf16x8 lbq[NLB][4];
+      if (LBALL) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) load_lb3(j, lbq[LBALL ? j : 0]);
+      } else if (NLB == 2) {
+        load_lb3(0, lbq[0]);
+      }
+      early();
+      if (KG == 2) lds_barrier();                    // (the K-group exchange's reads of this LDS are over)
       if (rankwave) {
 #pragma unroll
         for (int jj = FN - 2; jj < FN; ++jj) {
@@ -836,25 +874,19 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
             }
         }
       }
-      __syncthreads();
+      lds_barrier();
       bf16x8 la3[NB][4];
 #pragma unroll
       for (int io = 0; io < NB; ++io)
 #pragma unroll
         for (int c = 0; c < 4; ++c) la3[io][c] = c < nkc ? xt[((wr * FM + ib0_ + io) * 4 + c) * 64 + lane] : zero8;
-      if constexpr (CS) __syncthreads();             // (the staging passes reuse this LDS)
+      if constexpr (CS) lds_barrier();               // (the staging passes reuse this LDS)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
+        if (!LBALL && NLB == 2 && j + 1 < FN) load_lb3(j + 1, lbq[(j + 1) & 1]);
+        if (NLB == 1) load_lb3(j, lbq[0]);
         if (col0_of(j) >= nbase) continue;           // padding, rank fragments
-        const bool cok = col0_of(j) + l31 < nbase;
-        const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + 4 * half;
-        bf16x8 lb[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bf16x4 lo = (cok && c < nkc) ? *(const bf16x4*)(lbp + 16 * c) : zero4;
-          const bf16x4 hi = (cok && c < nkc) ? *(const bf16x4*)(lbp + 16 * c + 8) : zero4;
-          lb[c] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+        const bf16x8(&lb)[4] = lbq[LBALL ? j : (j & (NLB - 1))];
 #pragma unroll
         for (int io = 0; io < NB; ++io)
 #pragma unroll
@@ -866,22 +898,26 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     // (mode 2) keep-bit plane for the backward-data launch of the same layer (T2VGemm.lr_plane, fragment-major: the lane's 16 keep
     // bits of a fragment are one 16-bit word; a wave's 64 words of a fragment are one 128-byte line)
     unsigned short* plane = (masked && lr2 && p.lr_plane) ? (unsigned short*)((unsigned char*)p.lr_plane + (size_t)member * (((size_t)M * mwidth) >> 3)) : nullptr;
+    // keep bits of fragment (io, j): bit 4q + e = element (band row, fragment column 8q + 4 (lane >> 5) + e) kept.  32-bit quad
+    // indices (launch_w8: the mask matrix has < 2^34 elements); straight-line code — thr = 0 without a mask keeps everything.
+    // (Hashed in the prologue instead, under the first stages' latency, the 3 000 cycles were not hidden — the set-up already
+    // covers that latency — and the words cost registers through the K loop: profiles/r06_w8_epilogue_timeline.txt.)
+    unsigned rq[NB];
+#pragma unroll
+    for (int io = 0; io < NB; ++io) rq[io] = (unsigned)(((unsigned long long)rowg[io] * mwidth) >> 2);
+    const unsigned cq0 = (unsigned)(mcol0 + wc * TN + 4 * half) >> 2;
     auto finish = [&](int io, int j, const f32x16& tmp) {       // acc += sc * mask * tmp
       unsigned pw = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float t0 = sc * tmp[4 * q], t1 = sc * tmp[4 * q + 1], t2 = sc * tmp[4 * q + 2], t3 = sc * tmp[4 * q + 3];
-        if (masked) {
-          const unsigned long long idx = (unsigned long long)rowg[io] * mwidth + (unsigned)(mcol0 + col0_of(j) + 8 * q + 4 * half);
-          const DropQuad h = drop_quad(dkey, idx >> 2);
-          const bool k0 = (h.a & 0xffffu) >= dkey.thr, k1 = (h.a >> 16) >= dkey.thr, k2 = (h.b & 0xffffu) >= dkey.thr, k3 = (h.b >> 16) >= dkey.thr;
-          t0 = k0 ? t0 : 0.f;
-          t1 = k1 ? t1 : 0.f;
-          t2 = k2 ? t2 : 0.f;
-          t3 = k3 ? t3 : 0.f;
-          pw |= ((k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u)) << (4 * q);
-        }
-        acc[io][j][4 * q] += t0; acc[io][j][4 * q + 1] += t1; acc[io][j][4 * q + 2] += t2; acc[io][j][4 * q + 3] += t3;
+        const DropQuad h = drop_quad(dkey, (unsigned long long)(rq[io] + cq0 + (unsigned)(8 * j + 2 * q)));
+        pw |= (((h.a & 0xffffu) >= dkey.thr ? 1u : 0u) | ((h.a >> 16) >= dkey.thr ? 2u : 0u) | ((h.b & 0xffffu) >= dkey.thr ? 4u : 0u) |
+               ((h.b >> 16) >= dkey.thr ? 8u : 0u)) << (4 * q);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned km = (unsigned)__builtin_amdgcn_sbfe((int)pw, r, 1);                         // 0 / ~0
+        acc[io][j][r] += __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sc * tmp[r]) & km);
       }
       if (plane && rowg[io] < (unsigned)M)
         plane[(((size_t)((mcol0 + col0_of(j)) >> 5) * (size_t)M + rowg[io]) << 1) + half] = (unsigned short)pw;
@@ -891,7 +927,28 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       // 8s .. 8s+7 of a lane = ranks 16s + {4h .. 4h+3, 8+4h .. 8+4h+3} of tile row (lane & 31) — used as k slots 0..7 as they are
       bf16x8* xt = (bf16x8*)smem;                    // [WM * FM bands][2 k16 steps][64 lanes]
       const int wc_r = rk0 / TN, j_r = (rk0 - wc_r * TN) >> 5;
-      if (KG == 2) __syncthreads();                  // (the K-group exchange's reads of this LDS are over)
+      // LB rows of fragment j, unconditional loads (columns beyond the base columns read the last one — never stored; a k16 step
+      // beyond the rank re-reads step 0 — never multiplied), requested at the top of the phase (LBALL) or one fragment ahead
+      auto load_lb2 = [&](int j, bf16x8(&lb)[2]) {
+        const int cl = min(col0_of(j) + l31, nbase - 1);
+        const bf16_t* lbp = LB + (unsigned)(n0 + cl) * (unsigned)p.lr_ldb + 4 * half;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int o = ks < nk ? 16 * ks : 0;
+          const bf16x4 lo = *(const bf16x4*)(lbp + o);
+          const bf16x4 hi = *(const bf16x4*)(lbp + o + 8);
+          lb[ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      };
+      bf16x8 lbq[NLB][2];
+      if (LBALL) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) load_lb2(j, lbq[LBALL ? j : 0]);
+      } else if (NLB == 2) {
+        load_lb2(0, lbq[0]);
+      }
+      early();
+      if (KG == 2) lds_barrier();                    // (the K-group exchange's reads of this LDS are over)
       if (wc == wc_r) {
 #pragma unroll
         for (int jj = 0; jj < FN; ++jj) {
@@ -915,24 +972,18 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
             }
         }
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int io = 0; io < NB; ++io)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) la[io][ks] = ks < nk ? xt[((wr * FM + ib0_ + io) * 2 + ks) * 64 + lane] : zero8;
-      __syncthreads();                               // (the staging passes reuse this LDS)
+      if constexpr (CS) lds_barrier();               // (the staging passes reuse this LDS)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
+        if (!LBALL && NLB == 2 && j + 1 < FN) load_lb2(j + 1, lbq[(j + 1) & 1]);
+        if (NLB == 1) load_lb2(j, lbq[0]);
         if (col0_of(j) >= nbase) continue;           // rank fragment, padding
-        const bool cok = col0_of(j) + l31 < nbase;
-        const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + 4 * half;
-        bf16x8 lb[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x4 lo = (cok && ks < nk) ? *(const bf16x4*)(lbp + 16 * ks) : zero4;
-          const bf16x4 hi = (cok && ks < nk) ? *(const bf16x4*)(lbp + 16 * ks + 8) : zero4;
-          lb[ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+        const bf16x8(&lb)[2] = lbq[LBALL ? j : (j & (NLB - 1))];
 #pragma unroll
         for (int io = 0; io < NB; ++io) {
           f32x16 tmp;
@@ -971,25 +1022,41 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           v = v && (unsigned)vy < (unsigned)g.Hv && (unsigned)vx < (unsigned)g.Wv;
           src = (unsigned)((gn[io] * g.Hv + vy) * g.Wv + vx);
         }
+        // unconditional loads (a lane without a source row reads row 0, a k16 step beyond the rank re-reads step 0), zeroed by
+        // value selects: predicated loads went out one at a time, each behind the exec-mask merge of the one before
+        const unsigned srow = (v ? src : 0u) * (unsigned)p.lr_lda;
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks)
-          la[io][ks] = (v && ks < nk && 16 * ks + 8 * half < rp) ? *(const bf16x8*)(LA + src * (unsigned)p.lr_lda + 16 * ks + 8 * half) : zero8;
+        for (int ks = 0; ks < 3; ++ks) {
+          const bool kv = (ks < nk) & (16 * ks + 8 * half < rp);
+          const bf16x8 x = *(const bf16x8*)(LA + srow + (kv ? 16 * ks + 8 * half : 0));
+          la[io][ks] = (v & kv) ? x : zero8;
+        }
       }
     };
+    // LB rows of fragment j: columns beyond the tile's base columns read the last base column (their products are never stored)
     auto load_lb = [&](int j, int tap, bf16x8(&lb)[3]) {
-      const bool cok = col0_of(j) + l31 < nbase;
-      const bf16_t* lbp = LB + (unsigned)(n0 + col0_of(j) + l31) * (unsigned)p.lr_ldb + tap * rkp + 8 * half;
+      const int cl = min(col0_of(j) + l31, nbase - 1);
+      const bf16_t* lbp = LB + (unsigned)(n0 + cl) * (unsigned)p.lr_ldb + tap * rkp + 8 * half;
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) lb[ks] = (cok && ks < nk) ? *(const bf16x8*)(lbp + 16 * ks) : zero8;
+      for (int ks = 0; ks < 3; ++ks) lb[ks] = *(const bf16x8*)(lbp + (ks < nk ? 16 * ks : 0));
     };
     if (direct) {                                    // no mask, unit scale: the products go straight into the accumulators
       for (int tap = 0; tap < taps; ++tap) {
         load_la(tap);
+        bf16x8 lbq[NLB][3];
+        if (LBALL) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) load_lb(j, tap, lbq[LBALL ? j : 0]);
+        } else if (NLB == 2) {
+          load_lb(0, tap, lbq[0]);
+        }
+        if (tap == 0) early();
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
+          if (!LBALL && NLB == 2 && j + 1 < FN) load_lb(j + 1, tap, lbq[(j + 1) & 1]);
+          if (NLB == 1) load_lb(j, tap, lbq[0]);
           if (col0_of(j) >= nbase) continue;
-          bf16x8 lb[3];
-          load_lb(j, tap, lb);
+          const bf16x8(&lb)[3] = lbq[LBALL ? j : (j & (NLB - 1))];
 #pragma unroll
           for (int io = 0; io < NB; ++io) {
             acc[io][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb[0], la[io][0], acc[io][j], 0, 0, 0);
@@ -998,13 +1065,22 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           }
         }
       }
-    } else {                                         // masked / scaled: one tap (launch_w8 checks), fragment by fragment
-      load_la(0);
+    } else {                                         // masked / scaled: one tap (launch_w8 checks), fragment by fragment; the
+      load_la(0);                                    // next fragment's LB rows are requested before this one's mask is hashed
+      bf16x8 lbq[NLB][3];
+      if (LBALL) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) load_lb(j, 0, lbq[LBALL ? j : 0]);
+      } else if (NLB == 2) {
+        load_lb(0, 0, lbq[0]);
+      }
+      early();
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
+        if (!LBALL && NLB == 2 && j + 1 < FN) load_lb(j + 1, 0, lbq[(j + 1) & 1]);
+        if (NLB == 1) load_lb(j, 0, lbq[0]);
         if (col0_of(j) >= nbase) continue;
-        bf16x8 lb[3];
-        load_lb(j, 0, lb);
+        const bf16x8(&lb)[3] = lbq[LBALL ? j : (j & (NLB - 1))];
 #pragma unroll
         for (int io = 0; io < NB; ++io) {
           f32x16 tmp;
@@ -1040,7 +1116,10 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       const bf16_t* rbp = (const bf16_t*)p.rowbias;
       const float* biasp = (const float*)p.bias;
       const int half = lane >> 5;
-      // per-chunk operands, requested one fragment ahead of their use
+      // per-chunk operands, requested PD chunks ahead of their use.  Every request is an unconditional load: an absent operand
+      // reads the zero page (offset mask 0), a lane outside the tile reads row / column 0 — with the loads inside `if (ok)` /
+      // `if (bias)` branches and a `cur = nxt` hand-over the compiler drained vmcnt to 0 once per chunk, i.e. every chunk
+      // waited for the PREVIOUS chunk's store to be acknowledged and for its own operands' round trip (round 6, found in the ISA)
       struct Pre {
         float4 b0, b1;
         bf16x8 rb, rv;
@@ -1051,22 +1130,36 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
         ok = row < (unsigned)M && (ccol - n0) < nbase;
         rk = p.n_split > 0 && ccol >= p.n_split;
       };
+      const float* bias_q = biasp ? biasp : (const float*)g_w8_zero;
+      const bf16_t* rb_q = rbp ? rbp : (const bf16_t*)g_w8_zero;
+      const bf16_t* r_q = Rp ? Rp : (const bf16_t*)g_w8_zero;
+      const unsigned bias_m = biasp ? ~0u : 0u, rb_m = rbp ? ~0u : 0u, r_m = Rp ? ~0u : 0u;
+      unsigned rbrow[OWN];                               // row-bias row of a band's tile row (one division per band, not per chunk)
+#pragma unroll
+      for (int io = 0; io < OWN; ++io) {
+        rbrow[io] = 0;
+        if (rbp) rbrow[io] = min((unsigned)m0 + wr * TM + (ib0 + io) * 32 + (lane & 31), (unsigned)M - 1) / (unsigned)p.rows_per_rb * (unsigned)p.ldrb;
+      }
+      constexpr int NCH = 2 * OWN * FN, PD = 2;           // chunks; prefetch distance
+      // chunks whose residual rows are requested right after the K loop (the K-group tiles have the registers for it; the
+      // kernels without K groups spill with any)
+      constexpr int NEARLY = (KG == 2 && LR != 0) ? (NCH < 8 ? NCH : 8) : 0;
       auto prefetch = [&](int ch, Pre& pf) {
         unsigned row;
         int ccol;
         bool ok, rk;
-        chunk_pos((ch >> 1) / FN, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
-        if (ok && !rk) {
-          if (biasp) {
-            pf.b0 = *(const float4*)(biasp + ccol);
-            pf.b1 = *(const float4*)(biasp + ccol + 4);
-          }
-          if (rbp) pf.rb = *(const bf16x8*)(rbp + (row / (unsigned)p.rows_per_rb) * (unsigned)p.ldrb + ccol);
-          if (Rp) pf.rv = *(const bf16x8*)(Rp + row * (unsigned)p.ldr + ccol);
-        }
+        const int io = (ch >> 1) / FN;
+        chunk_pos(io, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
+        const bool use = ok & !rk;
+        const unsigned cu = use ? (unsigned)ccol : 0u, ru = use ? row : 0u;
+        pf.b0 = *(const float4*)(bias_q + (cu & bias_m));
+        pf.b1 = *(const float4*)(bias_q + ((cu & bias_m) + 4));
+        pf.rb = *(const bf16x8*)(rb_q + ((rbrow[io] + cu) & rb_m));
+        if (ch >= NEARLY) pf.rv = *(const bf16x8*)(r_q + ((ru * (unsigned)p.ldr + cu) & r_m));
       };
-      Pre cur, nxt;
-      if (KG == 2 && role == 0 && LR == 0) prefetch(0, cur);      // (in flight under the K-group exchange)
+      Pre pre[PD + 1];
+      bf16x8 rve[NEARLY > 0 ? NEARLY : 1];
+      if (KG == 2 && role == 0 && LR == 0) prefetch(0, pre[0]);      // (in flight under the K-group exchange)
       if constexpr (KG == 2) {
         constexpr int PER = OWN * FN * 4 * 64;        // float4 slots per (receiving group, wave pair)
         float4* X = (float4*)smem;
@@ -1088,7 +1181,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
 #pragma unroll
               for (int q = 0; q < 4; ++q) xs[((io * FN + j) * 4 + q) * 64] = quad(acc[io][j], q);
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int io = 0; io < OWN; ++io)
 #pragma unroll
@@ -1106,6 +1199,22 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
             }
       }
       if ((dbg & 8)) tl[5] = __builtin_readcyclecounter();
+      // the residual rows of the first NEARLY chunks are requested from inside the rank phase, as soon as its own operand loads
+      // are out (`early`, see rank_phase): the launches of a level move in lock-step, so every workgroup of the chip asks for its
+      // residual tile at the same moment and the chunk loop ran at HBM speed (profiles/r06_w8_epilogue_timeline_before.txt: 7 900
+      // cycles with a residual, 5 000 without); issued there the rows arrive under the phase's LDS / MFMA / VALU work.  (Requested
+      // before the K-group exchange, or ahead of younger loads that the phase waits for, they only moved the wait.)
+      auto early_rows = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < NEARLY; ++ch) {
+          unsigned row;
+          int ccol;
+          bool ok, rk;
+          chunk_pos((ch >> 1) / FN, (ch >> 1) % FN, 2 * (ch & 1), row, ccol, ok, rk);
+          const bool use = ok & !rk;
+          rve[ch] = *(const bf16x8*)(r_q + ((((use ? row : 0u) * (unsigned)p.ldr) + (use ? (unsigned)ccol : 0u)) & r_m));
+        }
+      };
       if (role != 0) {
         // slab slot of (wave, own band io, j, quad q, lane): coalesced 1 KiB per wave instruction
         const long long slot0 = ((long long)wave * OWN * FN * 4) * 64 + lane;
@@ -1185,13 +1294,22 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
       if (!writer) {
         if constexpr (LR != 0) {
           // (after the K-group exchange and the split-K reduction: the accumulators are complete — mode 2 multiplies them)
-          if (p.lr_mode != 0) rank_phase(ib0, std::integral_constant<int, OWN>{});
+          if (p.lr_mode != 0) rank_phase(ib0, std::integral_constant<int, OWN>{}, early_rows);
+          else early_rows();
+        } else {
+          early_rows();
         }
-        if (KG == 1 || role != 0 || LR != 0) prefetch(0, cur);    // (the slab reduction / the rank phase need the registers)
+        if (KG == 2 && (dbg & 8)) tl[6] = __builtin_readcyclecounter();       // (exchange / slab reduction / rank phase done)
+        if (KG == 1 || role != 0 || LR != 0) prefetch(0, pre[0]);    // (the slab reduction / the rank phase need the registers)
 #pragma unroll
-        for (int ch = 0; ch < 2 * OWN * FN; ++ch) {      // chunk = (fragment, quad pair)
+        for (int c = 1; c < PD; ++c)
+          if (c < NCH) prefetch(c, pre[c]);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {               // chunk = (fragment, quad pair)
           const int io = (ch >> 1) / FN, j = (ch >> 1) % FN, qp = 2 * (ch & 1);
-          if (ch + 1 < 2 * OWN * FN) prefetch(ch + 1, nxt);
+          if (ch + PD < NCH) prefetch(ch + PD, pre[(ch + PD) % (PD + 1)]);
+          Pre& cur = pre[ch % (PD + 1)];
+          if (ch < NEARLY) cur.rv = rve[ch];
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {                // (every lane takes part in the swap: before any row / column guard)
@@ -1206,35 +1324,28 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
           int ccol;
           bool ok, rk;
           chunk_pos(io, j, qp, row, ccol, ok, rk);
-          if (ok) {
-            if (alpha != 1.f) {
+          // straight-line arithmetic (absent operands are zeros, lanes outside the tile compute and do not store); only the
+          // stores sit behind the row / column guard (x + 0 differs from x only in the sign of an exact zero)
+          float w[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= alpha;
-            }
-            if (rk) {                                  // rank columns: second output block, alpha only
-              *(bf16x8*)((bf16_t*)p.D2 + row * (unsigned)p.ldd2 + (ccol - p.n_split)) = pack8bf(v);
-            } else {
-              if (biasp) {
-                v[0] += cur.b0.x; v[1] += cur.b0.y; v[2] += cur.b0.z; v[3] += cur.b0.w;
-                v[4] += cur.b1.x; v[5] += cur.b1.y; v[6] += cur.b1.z; v[7] += cur.b1.w;
-              }
-              if (rbp) {
+          for (int e = 0; e < 8; ++e) w[e] = v[e] * alpha;
+          const bf16x8 rkv = pack8bf(w);               // rank columns: second output block, alpha only
+          w[0] += cur.b0.x; w[1] += cur.b0.y; w[2] += cur.b0.z; w[3] += cur.b0.w;
+          w[4] += cur.b1.x; w[5] += cur.b1.y; w[6] += cur.b1.z; w[7] += cur.b1.w;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bf2f((unsigned short)cur.rb[e]);
-              }
-              if (act_silu) {
+          for (int e = 0; e < 8; ++e) w[e] += bf2f((unsigned short)cur.rb[e]);
+          if (act_silu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-              }
-              if (Rp) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += beta * bf2f((unsigned short)cur.rv[e]);
-              }
-              *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + ccol) = pack8bf(v);
-            }
+            for (int e = 0; e < 8; ++e) w[e] = silu_f(w[e]);
           }
-          if ((dbg & 8) && ch == 1) tl[6] = __builtin_readcyclecounter();
-          cur = nxt;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] += beta * bf2f((unsigned short)cur.rv[e]);
+          const bf16x8 ov = pack8bf(w);
+          if (ok) {
+            if (rk) *(bf16x8*)((bf16_t*)p.D2 + row * (unsigned)p.ldd2 + (ccol - p.n_split)) = rkv;
+            else *(bf16x8*)((bf16_t*)p.D + row * (unsigned)p.ldd + ccol) = ov;
+          }
+          if (KG == 1 && (dbg & 8) && ch == 1) tl[6] = __builtin_readcyclecounter();
         }
       }
     }
@@ -1265,7 +1376,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
   if constexpr (LR != 0) {
     // staged path: the term is added to ONE of the partial sums that meet later (K group 0 of split 0); mode 2 needs complete
     // accumulators and therefore KG == 1 and a single split (launch_w8)
-    if (p.lr_mode != 0 && (KG == 1 || kg == 0) && bz == 0) rank_phase(0, std::integral_constant<int, FM>{});
+    if (p.lr_mode != 0 && (KG == 1 || kg == 0) && bz == 0) rank_phase(0, std::integral_constant<int, FM>{}, [] {});
   }
   CsState cst;
   cs_init(cst, p, cs_mode, cact && !rankcol, m0, col, Nb);
@@ -1276,22 +1387,23 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
     const int ib = ps / WRP, h = ps % WRP;
     // residual chunks of this pass: requested now, consumed after the staging barriers
     bf16x8 rv[ITERS];                                // (cs_mode 2 excludes a residual: the same registers hold the x rows)
+    // (one batch of unconditional loads: a thread's rows outside the pass / the matrix read the last valid row and are not used)
     if (CX && role != 1) {
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
-        const int rl = r0 + RPI * it;
-        const unsigned row = (unsigned)m0 + tile_row(ib, h, rl);
-        if (rl < PROWS && row < (unsigned)M) rv[it] = *(const bf16x8*)(CX + row * (unsigned)p.cs_ldx + col);
+        const int rl = min(r0 + RPI * it, PROWS - 1);
+        const unsigned row = min((unsigned)m0 + tile_row(ib, h, rl), (unsigned)M - 1);
+        rv[it] = *(const bf16x8*)(CX + row * (unsigned)p.cs_ldx + col);
       }
     } else if (R) {
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
-        const int rl = r0 + RPI * it;
-        const unsigned row = (unsigned)m0 + tile_row(ib, h, rl);
-        if (rl < PROWS && row < (unsigned)M) rv[it] = *(const bf16x8*)(R + row * (unsigned)p.ldr + col);
+        const int rl = min(r0 + RPI * it, PROWS - 1);
+        const unsigned row = min((unsigned)m0 + tile_row(ib, h, rl), (unsigned)M - 1);
+        rv[it] = *(const bf16x8*)(R + row * (unsigned)p.ldr + col);
       }
     }
-    if (ps > 0) __syncthreads();
+    if (ps > 0) lds_barrier();                       // (LDS-only: the residual rows requested above stay in flight)
     const bool mine = (wr / WPP) == h;
     const int wrl = wr % WPP;
     if (mine && (KG == 1 || kg == 1)) {
@@ -1307,7 +1419,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
             *(float4*)(sC + rl * SB + cl) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
           }
     }
-    __syncthreads();
+    lds_barrier();
     if constexpr (KG == 2) {
       if (mine && kg == 0) {
 #pragma unroll
@@ -1324,7 +1436,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const T2VGemm p, const int
               *(float4*)(sC + rl * SB + cl) = t;
             }
       }
-      __syncthreads();
+      lds_barrier();
     }
     if ((dbg & 8) && ps == 0) tl[5] = __builtin_readcyclecounter();
     if (cact) {
@@ -1472,6 +1584,9 @@ int launch_w8(const T2VGemm& p, int nstep, int splits, hipStream_t s) {
                   "t2v_gemm_w8: lr_group_cols (mode 2 only) must divide N into at most 3 members of whole fragments");
     T2V_CHECK_ARG(p.lr_drop_p >= 0.f && p.lr_drop_p < 1.f, "t2v_gemm_w8: lr_drop_p must be in [0, 1)");
     T2V_CHECK_ARG((long long)p.N * p.lr_ldb < 0x7ff00000ll, "t2v_gemm_w8: lr_b too large for 32-bit offsets");
+    T2V_CHECK_ARG(p.lr_drop_p == 0.f || ((p.lr_group_cols > 0 ? p.lr_group_cols : p.N) % 8 == 0 &&
+                                         (long long)p.M * (p.lr_group_cols > 0 ? p.lr_group_cols : p.N) < (1ll << 34)),
+                  "t2v_gemm_w8: the mask matrix of a dropped rank-wide term must have a width of whole 8-column chunks and < 2^34 elements");
     if (p.lr_mode == 1) {
       T2V_CHECK_ARG(p.lr_a && p.lr_lda % 8 == 0 && p.lr_lda >= p.lr_rp && p.lr_taps >= 1, "t2v_gemm_w8: lr_mode 1 needs lr_a [rows, lr_lda >= lr_rp]");
       T2V_CHECK_ARG((long long)p.M * p.lr_lda < 0x7ff00000ll, "t2v_gemm_w8: lr_a too large for 32-bit offsets");
