@@ -12,7 +12,8 @@ namespace {
 // the kernel) => bit-reproducible statistics without a separate finalize launch.
 constexpr int GN_MAX_SPLIT = 256;
 
-template <bool BWD>
+// FLAGS (backward only; round 6, as in gn_apply below): bit 0 SiLU, bit 1 dropout, bit 2 parameter gradients — compile-time
+template <bool BWD, int FLAGS = 0>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, long long ldx,
                                                         const bf16_t* __restrict__ dy, long long lddy,
                                                         int rows_per_domain, int C, int G, const float* __restrict__ sums,
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                                                         unsigned* __restrict__ counters) {
   __shared__ float sval[256 * 17];
   __shared__ int s_last;   // per-thread (8 sums, 8 second sums), row stride 17 to dodge bank conflicts
-  const DropKey dkey = drop_key(drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull, drop_p);
+  constexpr bool SILU = (FLAGS & 1) != 0, DROP = (FLAGS & 2) != 0, PG = (FLAGS & 4) != 0;
+  const DropKey dkey = drop_key(DROP ? eff_seed(drop_seed_in, drop_epoch) : 0ull, drop_p);
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
           }
         }
       }
-      const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+      const float ks = DROP ? 1.f / (1.f - drop_p) : 1.f;
       constexpr int UN = 4;                 // independent 16-byte loads in flight per operand
       for (int r0 = rbeg + rl; r0 < rend; r0 += UN * rpp) {
         bf16x8 xq[UN], gq[UN];
@@ -89,20 +91,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
             }
           } else {
             const bf16x8 gv = gq[u];
-            const unsigned kb = drop_p > 0.f ? drop_bits8(dkey, (unsigned long long)row * C + cc * 8) : 0xffu;
+            const unsigned kb = DROP ? drop_bits8(dkey, (unsigned long long)row * C + cc * 8) : 0xffu;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               float xh = (bf2f((unsigned short)xv[e]) - mean[e]) * rstd[e];
               float dz = bf2f((unsigned short)gv[e]);
-              if (drop_p > 0.f) dz = ((kb >> e) & 1u) ? dz * ks : 0.f;
-              if (silu) {
+              if (DROP) dz = ((kb >> e) & 1u) ? dz * ks : 0.f;
+              if (SILU) {
                 float zz = xh * gm[e] + bt[e];
                 float sg = sigmoid_f(zz);
                 dz *= sg * (1.f + zz * (1.f - sg));
               }
               s0[e] += dz * gm[e];           // sum dxh
               s1[e] += dz * gm[e] * xh;      // sum dxh * xh
-              if (dgamma) {
+              if (PG) {
                 a0[e] += dz * xh;
                 a1[e] += dz;
               }
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
       }
     }
     __syncthreads();
-    if (BWD && dgamma) {
+    if (BWD && PG) {
       // Parameter gradients d(gamma), d(beta) (config C3): the row lanes of a chunk column are summed through LDS in lane
       // order and the workgroup writes ONE partial row [2][C] with plain stores (`dgamma` is the partial buffer here);
       // param_grad_reduce_kernel adds the workgroups' rows in index order.  The first version issued 16 float atomics per
@@ -203,7 +205,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 // grid (nsplit, ndomains) like the statistics pass: a thread owns ONE 8-channel chunk column and walks rows, so the
 // per-channel affine terms (mean, rstd, gamma, beta and the backward sums) are formed once in registers and the row loop
 // is pure streaming — four independent 16-byte loads in flight per operand.
-template <bool BWD>
+// FLAGS (round 6): bit 0 SiLU, bit 1 dropout, bit 2 (backward) a pass-through addend — compile-time, not run-time: as uniform
+// run-time flags every ELEMENT of the row loop carried its own `s_cbranch` around the transcendental / the select (8 per 16-byte
+// chunk, found in the ISA), which also kept the eight exp -> rcp chains of a chunk from interleaving.
+template <bool BWD, int FLAGS>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, long long ldx,
                                                         const bf16_t* __restrict__ dy, long long lddy,
                                                         bf16_t* __restrict__ y, long long ldy, int rows_per_domain, int C, int G,
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                         float eps, int silu, float drop_p, unsigned long long drop_seed_in,
                                                         const unsigned long long* __restrict__ drop_epoch,
                                                         const bf16_t* __restrict__ addend, long long ldadd) {
-  const DropKey dkey = drop_key(drop_p > 0.f ? eff_seed(drop_seed_in, drop_epoch) : 0ull, drop_p);
+  constexpr bool SILU = (FLAGS & 1) != 0, DROP = (FLAGS & 2) != 0, ADD = BWD && (FLAGS & 4) != 0;
+  const DropKey dkey = drop_key(DROP ? eff_seed(drop_seed_in, drop_epoch) : 0ull, drop_p);
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nchunks = C >> 3;
   const int tpr = min(nchunks, 256), rpp = 256 / tpr;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   const int rows_per_split = (rows_per_domain + gridDim.x - 1) / gridDim.x;
   const int rbeg = blockIdx.x * rows_per_split, rend = min(rows_per_domain, rbeg + rows_per_split);
   const float icnt = 1.f / ((float)rows_per_domain * cpg);
-  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const float ks = DROP ? 1.f / (1.f - drop_p) : 1.f;
   constexpr int UN = 4;
   for (int cb = 0; cb < ncb; ++cb) {
     const int cc = cb * tpr + tid % tpr;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         if (rr < rend) {
           xv[u] = *(const bf16x8*)(x + (base + rr) * ldx + cc * 8);
           if (BWD) gv[u] = *(const bf16x8*)(dy + (base + rr) * lddy + cc * 8);
-          if (BWD && addend) av[u] = *(const bf16x8*)(addend + (base + rr) * ldadd + cc * 8);
+          if (ADD) av[u] = *(const bf16x8*)(addend + (base + rr) * ldadd + cc * 8);
         }
       }
 #pragma unroll
@@ -273,26 +279,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         if (rr >= rend) continue;
         const long long row = base + rr;
         bf16x8 ov;
-        const unsigned kb = drop_p > 0.f ? drop_bits8(dkey, (unsigned long long)row * C + cc * 8) : 0xffu;
+        const unsigned kb = DROP ? drop_bits8(dkey, (unsigned long long)row * C + cc * 8) : 0xffu;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float out;
           if (!BWD) {
             float zz = bf2f((unsigned short)xv[u][e]) * gm[e] + bt[e];
-            if (silu) zz = silu_f(zz);
-            if (drop_p > 0.f) zz = ((kb >> e) & 1u) ? zz * ks : 0.f;
+            if (SILU) zz = silu_f(zz);
+            if (DROP) zz = ((kb >> e) & 1u) ? zz * ks : 0.f;
             out = zz;
           } else {
             const float xh = (bf2f((unsigned short)xv[u][e]) - mu[e]) * rs[e];
             float dz = bf2f((unsigned short)gv[u][e]);
-            if (drop_p > 0.f) dz = ((kb >> e) & 1u) ? dz * ks : 0.f;
-            if (silu) {
+            if (DROP) dz = ((kb >> e) & 1u) ? dz * ks : 0.f;
+            if (SILU) {
               const float zz = xh * gm[e] + bt[e];
               const float sg = sigmoid_f(zz);
               dz *= sg * (1.f + zz * (1.f - sg));
             }
             out = rs[e] * (dz * gm[e] - b1[e] - xh * b2[e]);
-            if (addend) out += bf2f((unsigned short)av[u][e]);      // gradient of a pass-through (residual) use of x
+            if (ADD) out += bf2f((unsigned short)av[u][e]);      // gradient of a pass-through (residual) use of x
           }
           ov[e] = (short)f2bf(out);
         }
@@ -649,9 +655,17 @@ extern "C" int t2v_gn_apply(const void* x, long long ldx, void* y, long long ldy
   T2V_CHECK_ARG(x && y && sums && gamma && beta && ldy % 8 == 0, "t2v_gn_apply: bad args");
   T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_apply: bad domain grid");
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
-  T2V_LAUNCH(gn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr,
-                     0, (bf16_t*)y, ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch,
-                     (const bf16_t*)nullptr, 0LL);
+#define T2V_GN_FWD(F_)                                                                                                         \
+  T2V_LAUNCH((gn_apply_kernel<false, F_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, nullptr, 0, (bf16_t*)y, \
+             ldy, rows_per_domain, C, G, sums, nullptr, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch,                 \
+             (const bf16_t*)nullptr, 0LL)
+  switch ((silu ? 1 : 0) | (drop_p > 0.f ? 2 : 0)) {
+    case 0: T2V_GN_FWD(0); break;
+    case 1: T2V_GN_FWD(1); break;
+    case 2: T2V_GN_FWD(2); break;
+    default: T2V_GN_FWD(3); break;
+  }
+#undef T2V_GN_FWD
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
@@ -683,14 +697,24 @@ extern "C" int t2v_gn_bwd_stats(const void* x, long long ldx, const void* dy, lo
     pg = pg_workspace;
     T2V_CHECK_ARG(pg, "t2v_gn_bwd_stats: dgamma / dbeta need pg_workspace (t2v_gn_bwd_pg_floats() = %lld floats)", (long long)nwg * 2 * C);
   }
-  if (dgamma)
-    T2V_LAUNCH_FIRST(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch, workspace + GN_MAX_DOMAINS, pg,
-                     dbeta, bsums, counters);
-  else
-    T2V_LAUNCH(gn_stats_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy,
-                     lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch, workspace + GN_MAX_DOMAINS, pg,
-                     dbeta, bsums, counters);
+#define T2V_GN_BSTATS(F_)                                                                                                        \
+  do {                                                                                                                           \
+    if (dgamma)                                                                                                                  \
+      T2V_LAUNCH_FIRST((gn_stats_kernel<true, (F_) | 4>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,           \
+                       (const bf16_t*)dy, lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed,           \
+                       t2v_drop_epoch, workspace + GN_MAX_DOMAINS, pg, dbeta, bsums, counters);                                  \
+    else                                                                                                                         \
+      T2V_LAUNCH((gn_stats_kernel<true, (F_)>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, \
+                 lddy, rows_per_domain, C, G, sums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch,                    \
+                 workspace + GN_MAX_DOMAINS, pg, dbeta, bsums, counters);                                                        \
+  } while (0)
+  switch ((silu ? 1 : 0) | (drop_p > 0.f ? 2 : 0)) {
+    case 0: T2V_GN_BSTATS(0); break;
+    case 1: T2V_GN_BSTATS(1); break;
+    case 2: T2V_GN_BSTATS(2); break;
+    default: T2V_GN_BSTATS(3); break;
+  }
+#undef T2V_GN_BSTATS
   T2V_CHECK_LAUNCH();
   if (dgamma) {
     T2V_LAUNCH_LAST(param_grad_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)pg, nwg, C, dgamma, dbeta);
@@ -709,9 +733,21 @@ extern "C" int t2v_gn_bwd_apply(const void* x, long long ldx, const void* dy, lo
                 "t2v_gn_bwd_apply: bad args");
   T2V_CHECK_ARG(ndomains > 0 && ndomains <= 65535 && rows_per_domain > 0, "t2v_gn_bwd_apply: bad domain grid");
   dim3 grid(gn_apply_splits(ndomains, rows_per_domain, C), ndomains);
-  T2V_LAUNCH(gn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                     (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, rows_per_domain, C, G, sums, bsums, gamma, beta, eps,
-                     silu, drop_p, drop_seed, t2v_drop_epoch, (const bf16_t*)addend, ldadd);
+#define T2V_GN_BWD(F_)                                                                                                         \
+  T2V_LAUNCH((gn_apply_kernel<true, F_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, \
+             (bf16_t*)dx, lddx, rows_per_domain, C, G, sums, bsums, gamma, beta, eps, silu, drop_p, drop_seed, t2v_drop_epoch,     \
+             (const bf16_t*)addend, ldadd)
+  switch ((silu ? 1 : 0) | (drop_p > 0.f ? 2 : 0) | (addend ? 4 : 0)) {
+    case 0: T2V_GN_BWD(0); break;
+    case 1: T2V_GN_BWD(1); break;
+    case 2: T2V_GN_BWD(2); break;
+    case 3: T2V_GN_BWD(3); break;
+    case 4: T2V_GN_BWD(4); break;
+    case 5: T2V_GN_BWD(5); break;
+    case 6: T2V_GN_BWD(6); break;
+    default: T2V_GN_BWD(7); break;
+  }
+#undef T2V_GN_BWD
   T2V_CHECK_LAUNCH();
   return T2V_OK;
 }
