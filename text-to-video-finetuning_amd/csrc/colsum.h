@@ -52,19 +52,27 @@ __device__ __forceinline__ void cs_add(CsState& c, int mode, const bf16x8& ov, c
       c.s2[e] += q * q;
     }
   } else if (mode == 2) {                          // the two sums of gn_stats_kernel<true> (norm.hip), same arithmetic
+    // (the uniform flags are tested once per chunk, not per element — round 6, see gn_apply_kernel in norm.hip; without a mask
+    //  kb = all ones and ks = 1, so the select needs no flag at all)
     const unsigned kb = drop ? drop_bits8(c.dk, (unsigned long long)row * (unsigned)c.width + (unsigned)col) : 0xffu;
+    float xh[8], dz[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float xh = (bf2f((unsigned short)xrow[e]) - c.mu[e]) * c.rs[e];
-      float dz = bf2f((unsigned short)ov[e]);
-      if (drop) dz = ((kb >> e) & 1u) ? dz * c.ks : 0.f;
-      if (silu) {
-        const float zz = xh * c.g[e] + c.b[e];
+      xh[e] = (bf2f((unsigned short)xrow[e]) - c.mu[e]) * c.rs[e];
+      dz[e] = ((kb >> e) & 1u) ? bf2f((unsigned short)ov[e]) * c.ks : 0.f;
+    }
+    if (silu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float zz = xh[e] * c.g[e] + c.b[e];
         const float sg = sigmoid_f(zz);
-        dz *= sg * (1.f + zz * (1.f - sg));
+        dz[e] *= sg * (1.f + zz * (1.f - sg));
       }
-      c.s1[e] += dz * c.g[e];
-      c.s2[e] += dz * c.g[e] * xh;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      c.s1[e] += dz[e] * c.g[e];
+      c.s2[e] += dz[e] * c.g[e] * xh[e];
     }
   }
 }
