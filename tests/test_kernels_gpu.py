@@ -1037,6 +1037,51 @@ def test_w8_configurations_match_the_table_kernels(M, N, rc, K, taps, res):
     assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "split-K counters must be left zero"
 
 
+@pytest.mark.parametrize("M,N,K,bias,rb,act,res", [(300, 320, 320, 0, 0, 0, 0), (300, 320, 320, 0, 1, 1, 1), (1000, 640, 640, 1, 1, 1, 0),
+                                                    (256, 200, 320, 0, 0, 1, 1), (2048, 1280, 1280, 1, 1, 0, 1)])
+def test_w8_register_epilogue_operand_combinations(M, N, K, bias, rb, act, res):
+    """The register epilogue of the 8-wave kernels requests bias / row-bias / residual with UNCONDITIONAL loads two chunks ahead (an
+    absent operand reads a zero page, lanes outside the tile read row / column 0 — gemm_w8.hip, round 6): every combination of
+    present / absent operands, with SiLU, on ragged row counts and a column count that is not a whole tile, against fp32 torch on the
+    bf16 operands (the epilogue of ops/conv.py:forward: act(x W^T + bias + rowbias[image]) + residual)."""
+    import ctypes as C
+    import t2v_amd.functional as F
+    import t2v_amd.native as nv
+    g = torch.Generator().manual_seed(M + N + 7 * bias + 3 * rb)
+    a = _bf(torch.randn(M, K, generator=g)).cuda()
+    w = _bf(torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    nimg = 4 if M % 4 == 0 else 3
+    rows_per = M // nimg if M % nimg == 0 else M
+    rbt = _bf(torch.randn(M // rows_per, N, generator=g)).cuda() if rb else None
+    r = _bf(torch.randn(M, N, generator=g)).cuda() if res else None
+    d = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    kw = dict(M=M, N=N, K=K, A=a.data_ptr(), lda=K, B=w.data_ptr(), ldb=K, D=d.data_ptr(), ldd=N, bias=nv.ptr(b), a_mode=0, geom=None,
+              rowbias=nv.ptr(rbt), ldrb=N if rb else 0, rows_per_rb=rows_per if rb else 0, R=nv.ptr(r), ldr=N if res else 0,
+              act=1 if act else 0)
+    desc = F.make_gemm(**kw)
+    ref = a.float() @ w.float().T
+    if bias:
+        ref = ref + b
+    if rb:
+        ref = ref + rbt.float().repeat_interleave(rows_per, 0)
+    if act:
+        ref = torch.nn.functional.silu(ref)
+    if res:
+        ref = ref + r.float()
+    scale = float(ref.abs().max())
+    for cfg in (12, 13, 14, 16, 17, 18, 19, 20, 21, 22):          # the configurations with a register epilogue
+        for nstep, splits in ((0, 1), (160, 1), (0, 2)):
+            d.fill_(float("nan"))
+            nv.call("t2v_gemm_w8", C.byref(desc), cfg, nstep, splits, nv.stream())
+            torch.cuda.synchronize()
+            assert torch.isfinite(d.float()).all(), (cfg, nstep, splits)
+            err = float((d.float() - ref).abs().max()) / scale
+            assert err < 1.2e-2, (cfg, nstep, splits, err)
+    ws = F._gemm_workspace()
+    assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "split-K counters must be left zero"
+
+
 @pytest.mark.parametrize("M,N,K,taps,rp,res,p_drop", [(512, 320, 320, 1, 16, 1, 0.1), (1152, 640, 1920, 3, 16, 0, 0.1),
                                                        (1152, 320, 2880, 9, 16, 1, 0.1), (300, 1280, 1280, 1, 32, 0, 0.25),
                                                        (2048, 128, 1152, 9, 8, 0, 0.1), (256, 2560, 320, 1, 24, 0, 0.0)])
