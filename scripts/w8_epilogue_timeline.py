@@ -2,7 +2,7 @@
 (M x 320 x 320 + 16 ranks, bias, residual, mask, keep-bit plane) on the two configurations the step uses, timed in a graph
 of ten launches and stamped per workgroup (T2V_W8_DBG=8: set-up / first stage / K loop / exchange + rank phase / output chunks /
 store drain), next to the same launch without the mask, without the residual, and without the term (rank columns only).
-    T2V_W8_DBG=8 python scripts/w8_epilogue_timeline.py [M]"""
+    T2V_W8_DBG=8 python scripts/w8_epilogue_timeline.py [M [N [K]]]"""
 import ctypes as C
 import os
 import sys
@@ -53,7 +53,9 @@ def stamps(launch):
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-    N, K, rp = 320, 320, 16
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else N
+    rp = 16
     lib = nv.lib()
     g = torch.Generator().manual_seed(1)
     # two operand sets so that consecutive launches do not find their activations in the L2s
@@ -92,7 +94,7 @@ def main():
                 rc = lib.t2v_gemm_w8(C.byref(ds[i & 1]), cfg, 0, 1, nv.stream())
                 assert rc == 0, lib.t2v_last_error().decode()
             us = timeit(launch)
-            line = f"M={M} {name:28s} cfg {cfg}: {us:6.1f} us"
+            line = f"M={M} N={N} K={K} {name:28s} cfg {cfg}: {us:6.1f} us"
             if dbg & 8:
                 line += " | " + stamps(lambda: launch(0))
             print(line, flush=True)
